@@ -1,0 +1,162 @@
+// oracle_capi.cpp -- ctypes-friendly C entry points of the CPU ORACLE (liboracle_hnsw.so).
+//
+// TEST INFRASTRUCTURE ONLY: loaded by tests/, __graft_entry__.smoke() and the
+// `cpu_baseline` leg of bench.py.  Nothing under hnswlib-rs_amd/ links or dlopens this.
+#include <chrono>
+#include <cstring>
+#include <string>
+#include "hnsw_oracle.hpp"
+#include "hnswio_oracle.hpp"
+
+using namespace oracle;
+
+static thread_local std::string g_err;
+#define ORC_TRY try {
+#define ORC_CATCH(ret)                                \
+    }                                                 \
+    catch (const std::exception& e) {                 \
+        g_err = e.what();                             \
+        return ret;                                   \
+    }
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+void* orc_new(size_t max_nb_conn, size_t max_elements, size_t max_layer, size_t ef_c, int dist) {
+    ORC_TRY
+    return new Hnsw(max_nb_conn, max_elements, max_layer, ef_c, (DistKind)dist);
+    ORC_CATCH(nullptr)
+}
+void orc_free(void* h) { delete static_cast<Hnsw*>(h); }
+void orc_modify_level_scale(void* h, double f) { static_cast<Hnsw*>(h)->modify_level_scale(f); }
+void orc_set_extend_candidates(void* h, int flag) { static_cast<Hnsw*>(h)->extend_candidates = flag != 0; }
+void orc_set_keeping_pruned(void* h, int flag) { static_cast<Hnsw*>(h)->keep_pruned = flag != 0; }
+size_t orc_get_nb_point(void* h) { return static_cast<Hnsw*>(h)->nb_point; }
+size_t orc_get_layer_nb_point(void* h, size_t l) { return static_cast<Hnsw*>(h)->get_layer_nb_point(l); }
+int orc_get_max_level_observed(void* h) { return static_cast<Hnsw*>(h)->get_max_level_observed(); }
+size_t orc_get_dimension(void* h) { return static_cast<Hnsw*>(h)->data_dimension; }
+
+// Hnsw::insert for n points in order (serial; src/hnsw.rs:1069-1071).
+int orc_insert_batch(void* hv, const float* data, size_t n, size_t d, const size_t* ids) {
+    ORC_TRY
+    Hnsw* h = static_cast<Hnsw*>(hv);
+    for (size_t i = 0; i < n; ++i) h->insert(data + i * d, d, ids ? ids[i] : i);
+    return 0;
+    ORC_CATCH(-1)
+}
+
+// Hnsw::search (src/hnsw.rs:1597).  Outputs hold up to k entries; *count = number returned.
+int orc_search(void* hv, const float* q, size_t d, size_t k, size_t ef, uint64_t* out_ids, float* out_dists,
+               uint8_t* out_layer, int32_t* out_rank, uint32_t* count) {
+    ORC_TRY
+    Hnsw* h = static_cast<Hnsw*>(hv);
+    if (h->data_dimension && d != h->data_dimension) throw std::runtime_error("search: dimension mismatch");
+    auto r = h->search(q, k, ef);
+    for (size_t i = 0; i < r.size(); ++i) {
+        out_ids[i] = r[i].d_id;
+        out_dists[i] = r[i].distance;
+        if (out_layer) out_layer[i] = r[i].p_id.layer;
+        if (out_rank) out_rank[i] = r[i].p_id.rank;
+    }
+    *count = (uint32_t)r.size();
+    return 0;
+    ORC_CATCH(-1)
+}
+
+// Hnsw::parallel_search (src/hnsw.rs:1612-1635).  `queries` is nq x d row-major; each row is
+// first copied into its own heap vector (the reference takes &[Vec<T>]).  Only the
+// parallel_search call itself is timed (*elapsed_s), like
+// examples/ann-sift1m-128-euclidean.rs:148-164.  counters (may be null) = {n_dist, n_expand,
+// n_ids_read} summed over all queries.
+int orc_parallel_search(void* hv, const float* queries, size_t nq, size_t d, size_t k, size_t ef, int nthreads,
+                        uint64_t* out_ids, float* out_dists, uint8_t* out_layer, int32_t* out_rank,
+                        uint32_t* out_counts, uint64_t* counters, double* elapsed_s) {
+    ORC_TRY
+    Hnsw* h = static_cast<Hnsw*>(hv);
+    if (h->data_dimension && d != h->data_dimension) throw std::runtime_error("search: dimension mismatch");
+    std::vector<std::vector<float>> datas(nq);
+    for (size_t i = 0; i < nq; ++i) datas[i].assign(queries + i * d, queries + (i + 1) * d);
+    Counters total;
+    auto t0 = std::chrono::steady_clock::now();
+    auto ans = h->parallel_search(datas, k, ef, nthreads, counters ? &total : nullptr);
+    auto t1 = std::chrono::steady_clock::now();
+    if (elapsed_s) *elapsed_s = std::chrono::duration<double>(t1 - t0).count();
+    for (size_t i = 0; i < nq; ++i) {
+        const auto& r = ans[i];
+        for (size_t j = 0; j < r.size(); ++j) {
+            out_ids[i * k + j] = r[j].d_id;
+            out_dists[i * k + j] = r[j].distance;
+            if (out_layer) out_layer[i * k + j] = r[j].p_id.layer;
+            if (out_rank) out_rank[i * k + j] = r[j].p_id.rank;
+        }
+        out_counts[i] = (uint32_t)r.size();
+    }
+    if (counters) {
+        counters[0] = total.n_dist;
+        counters[1] = total.n_expand;
+        counters[2] = total.n_ids_read;
+    }
+    return 0;
+    ORC_CATCH(-1)
+}
+
+// AnnT::file_dump (src/api.rs:70-93) without the unique-name logic: overwrites.
+int orc_file_dump(void* hv, const char* dir, const char* basename) {
+    ORC_TRY
+    file_dump(*static_cast<Hnsw*>(hv), dir, basename);
+    return 1;
+    ORC_CATCH(-1)
+}
+// HnswIo::new(dir, basename).load_hnsw::<f32, D>()
+void* orc_load(const char* dir, const char* basename, int dist) {
+    ORC_TRY
+    return load_hnsw(dir, basename, (DistKind)dist).release();
+    ORC_CATCH(nullptr)
+}
+
+// Distance<f32>::eval of the restated anndists metrics, for arithmetic tests.
+float orc_dist(int kind, const float* a, const float* b, size_t d) {
+    ORC_TRY
+    return dist_eval((DistKind)kind, a, b, d);
+    ORC_CATCH(NAN)
+}
+void orc_l2_normalize(float* v, size_t d) { l2_normalize(v, d); }
+
+// Level generator stream (for checking the product builder draws the same levels).
+void orc_levels(size_t max_nb_conn, double scale_factor, size_t maxlevel, size_t n, uint8_t* out) {
+    LayerGenerator g(max_nb_conn, scale_factor, maxlevel);
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)g.generate();
+}
+
+// Raw BinaryHeap restatement driver for unit tests: push all values, then either pop `npop`
+// times (mode 0: out = popped values) or into_sorted_vec (mode 1).  `tags` travel with the
+// values so tie order is observable.
+int orc_heap_exercise(const float* vals, const int32_t* tags, size_t n, int mode, size_t npop, float* out_vals,
+                      int32_t* out_tags) {
+    ORC_TRY
+    RustBinaryHeap hp;
+    float dummy[1] = {0.f};
+    for (size_t i = 0; i < n; ++i) {
+        auto p = std::make_shared<Point>(dummy, 1, (size_t)tags[i], PointId{0, tags[i]});
+        hp.push(std::make_shared<PointWithOrder>(p, vals[i]));
+    }
+    if (mode == 0) {
+        for (size_t i = 0; i < npop; ++i) {
+            PWO x;
+            if (!hp.pop(x)) return (int)i;
+            out_vals[i] = x->dist_to_ref;
+            out_tags[i] = x->point_ref->p_id.rank;
+        }
+        return (int)npop;
+    }
+    auto v = hp.into_sorted_vec();
+    for (size_t i = 0; i < v.size(); ++i) {
+        out_vals[i] = v[i]->dist_to_ref;
+        out_tags[i] = v[i]->point_ref->p_id.rank;
+    }
+    return (int)v.size();
+    ORC_CATCH(-1)
+}
+
+}  // extern "C"
