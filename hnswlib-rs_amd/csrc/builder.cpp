@@ -1,0 +1,500 @@
+// builder.cpp -- see builder.hpp.  Compile with -ffp-contract=off: in reference-order mode the
+// stored edge distances must equal the crate's scalar arithmetic bit for bit.
+#include "builder.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <unordered_set>
+
+#include "hnswio.hpp"
+
+namespace hnswgpu {
+
+// ---------------------------------------------------------------------------------------
+// Distance<f32>::eval on the host (anndists 0.1, default scalar build).
+// ---------------------------------------------------------------------------------------
+namespace {
+
+float l2_ref(const float* a, const float* b, size_t d) {
+    float norm = 0.f;
+    for (size_t i = 0; i < d; ++i) {
+        float t = a[i] - b[i];
+        norm = norm + t * t;
+    }
+    return std::sqrt(norm);
+}
+float l1_ref(const float* a, const float* b, size_t d) {
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) s = s + std::fabs(a[i] - b[i]);
+    return s;
+}
+float cosine_ref(const float* a, const float* b, size_t d) {
+    double s0 = 0., s1 = 0., s2 = 0.;
+    for (size_t i = 0; i < d; ++i) {
+        float ab = a[i] * b[i], aa = a[i] * a[i], bb = b[i] * b[i];
+        s0 = s0 + (double)ab;
+        s1 = s1 + (double)aa;
+        s2 = s2 + (double)bb;
+    }
+    if (s1 > 0. && s2 > 0.) return (float)std::max(1. - s0 / std::sqrt(s1 * s2), 0.);
+    return 0.f;
+}
+float dot_ref(const float* a, const float* b, size_t d) {
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) s = s + a[i] * b[i];
+    return std::max(1.f - s, 0.f);
+}
+
+// "fast" mode: 8 vertical accumulators over floor(d/8)*8 elements, horizontal add, scalar tail --
+// the summation order of the crate's simdeez_f (AVX2) build.  Lane arithmetic is independent of
+// the vector width the compiler picks, so both clones return the same bits.
+__attribute__((target_clones("avx2", "default"))) float l2_fast(const float* a, const float* b, size_t d) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= d; i += 8)
+        for (int j = 0; j < 8; ++j) {
+            float t = a[i + j] - b[i + j];
+            acc[j] += t * t;
+        }
+    float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; i < d; ++i) {
+        float t = a[i] - b[i];
+        s += t * t;
+    }
+    return std::sqrt(s);
+}
+__attribute__((target_clones("avx2", "default"))) float dot_fast(const float* a, const float* b, size_t d) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= d; i += 8)
+        for (int j = 0; j < 8; ++j) acc[j] += a[i + j] * b[i + j];
+    float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; i < d; ++i) s += a[i] * b[i];
+    return std::max(1.f - s, 0.f);
+}
+__attribute__((target_clones("avx2", "default"))) float l1_fast(const float* a, const float* b, size_t d) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= d; i += 8)
+        for (int j = 0; j < 8; ++j) acc[j] += std::fabs(a[i + j] - b[i + j]);
+    float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (; i < d; ++i) s += std::fabs(a[i] - b[i]);
+    return s;
+}
+__attribute__((target_clones("avx2", "default"))) float cosine_fast(const float* a, const float* b, size_t d) {
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 4 <= d; i += 4)
+        for (int j = 0; j < 4; ++j) {
+            s0[j] += (double)(a[i + j] * b[i + j]);
+            s1[j] += (double)(a[i + j] * a[i + j]);
+            s2[j] += (double)(b[i + j] * b[i + j]);
+        }
+    double t0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), t1 = (s1[0] + s1[1]) + (s1[2] + s1[3]),
+           t2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    for (; i < d; ++i) {
+        t0 += (double)(a[i] * b[i]);
+        t1 += (double)(a[i] * a[i]);
+        t2 += (double)(b[i] * b[i]);
+    }
+    if (t1 > 0. && t2 > 0.) return (float)std::max(1. - t0 / std::sqrt(t1 * t2), 0.);
+    return 0.f;
+}
+
+struct SpinGuard {
+    std::atomic<uint8_t>& l;
+    explicit SpinGuard(std::atomic<uint8_t>& x) : l(x) {
+        while (l.exchange(1, std::memory_order_acquire)) {
+            while (l.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+        }
+    }
+    ~SpinGuard() { l.store(0, std::memory_order_release); }
+};
+
+struct EdgeLess {
+    bool operator()(const Edge& a, const Edge& b) const { return a.dist < b.dist; }
+};
+struct EdgeGreater {
+    bool operator()(const Edge& a, const Edge& b) const { return a.dist > b.dist; }
+};
+
+}  // namespace
+
+struct GraphBuilder::Node {
+    std::atomic<uint8_t> lock{0};
+    uint8_t level = 0;
+    int32_t rank = 0;
+    uint64_t origin = 0;
+    std::vector<Edge> l0;                      // neighbours[0]
+    std::unique_ptr<std::vector<Edge>[]> up;   // neighbours[1..15], allocated on first use
+    std::vector<Edge>& list(unsigned l) {
+        if (l == 0) return l0;
+        if (!up) up.reset(new std::vector<Edge>[NB_LAYER_MAX - 1]);
+        return up[l - 1];
+    }
+    const std::vector<Edge>* list_if(unsigned l) const {
+        if (l == 0) return &l0;
+        return up ? &up[l - 1] : nullptr;
+    }
+};
+
+struct GraphBuilder::Tls {
+    std::vector<uint32_t> stamp;
+    uint32_t epoch = 0;
+    std::vector<Edge> cand_heap, res_heap, nbuf, res, sel, tmp, discarded;
+    void begin_visit(size_t n) {
+        if (stamp.size() < n) stamp.resize(n, 0);
+        if (++epoch == 0) {
+            std::fill(stamp.begin(), stamp.end(), 0);
+            epoch = 1;
+        }
+    }
+    bool visit(uint32_t id) {  // true if newly visited
+        if (stamp[id] == epoch) return false;
+        stamp[id] = epoch;
+        return true;
+    }
+};
+
+GraphBuilder::Node& GraphBuilder::node(uint32_t id) const { return chunks_[id >> 16][id & (CHUNK - 1)]; }
+
+GraphBuilder::GraphBuilder(const BuildParams& p) : p_(p) {
+    max_layer_ = (unsigned)std::min<uint64_t>(NB_LAYER_MAX, p.max_layer);  // src/hnsw.rs:778
+    if (max_layer_ == 0) max_layer_ = 1;
+    double f = std::min(1.0, std::max(0.2, p.level_scale_factor));          // src/hnsw.rs:884-904
+    scale_ = f / std::log((double)p.max_nb_connection);                      // src/hnsw.rs:327
+    for (auto& a : layer_inserted_) a.store(0);
+    layer_rank_next_.fill(0);
+}
+GraphBuilder::~GraphBuilder() = default;
+
+float GraphBuilder::eval(const float* a, const float* b) const {
+    if (!p_.fast_arithmetic) {
+        switch (p_.dist) {
+            case DIST_L2: return l2_ref(a, b, d_);
+            case DIST_COSINE: return cosine_ref(a, b, d_);
+            case DIST_DOT: return dot_ref(a, b, d_);
+            default: return l1_ref(a, b, d_);
+        }
+    }
+    switch (p_.dist) {
+        case DIST_L2: return l2_fast(a, b, d_);
+        case DIST_COSINE: return cosine_fast(a, b, d_);
+        case DIST_DOT: return dot_fast(a, b, d_);
+        default: return l1_fast(a, b, d_);
+    }
+}
+
+// LayerGenerator::generate (src/hnsw.rs:363-374) on the documented SplitMix64(397) stream.
+size_t GraphBuilder::draw_level() {
+    auto next = [&]() {
+        uint64_t z = (rng_state_ += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    double xsi = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+    double level = -std::log(xsi) * scale_;
+    double fl = std::floor(level);
+    size_t ulevel = (fl >= (double)max_layer_ || !(fl == fl)) ? max_layer_ : (size_t)fl;
+    if (ulevel >= max_layer_) ulevel = (size_t)(next() % (uint64_t)max_layer_);
+    return ulevel;
+}
+
+void GraphBuilder::read_list(uint32_t id, unsigned layer, std::vector<Edge>& out) const {
+    Node& nd = node(id);
+    SpinGuard g(nd.lock);
+    const std::vector<Edge>* l = nd.list_if(layer);
+    if (l) out.assign(l->begin(), l->end());
+    else out.clear();
+}
+
+// search_layer, unfiltered (src/hnsw.rs:922-1064) with flat heaps.  Result ascending by distance.
+void GraphBuilder::search_layer(const float* q, uint32_t entry, size_t ef, unsigned layer, Tls& t,
+                                std::vector<Edge>& out_sorted) {
+    out_sorted.clear();
+    if (layer_inserted_[layer].load(std::memory_order_acquire) == 0) return;  // :942-946
+    auto& C = t.cand_heap;  // min-heap on dist
+    auto& R = t.res_heap;   // max-heap on dist
+    C.clear();
+    R.clear();
+    t.begin_visit(n_);
+    float d0 = eval(q, vec(entry));
+    t.visit(entry);
+    C.push_back({entry, d0});
+    R.push_back({entry, d0});
+    while (!C.empty()) {
+        std::pop_heap(C.begin(), C.end(), EdgeGreater());
+        Edge c = C.back();
+        C.pop_back();
+        if (c.dist > R.front().dist) break;  // :981-993
+        read_list(c.id, layer, t.nbuf);
+        for (const Edge& e : t.nbuf) {
+            if (!t.visit(e.id)) continue;
+            float de = eval(q, vec(e.id));
+            if (de < R.front().dist || R.size() < ef) {
+                C.push_back({e.id, de});
+                std::push_heap(C.begin(), C.end(), EdgeGreater());
+                R.push_back({e.id, de});
+                std::push_heap(R.begin(), R.end(), EdgeLess());
+                if (R.size() > ef) {
+                    std::pop_heap(R.begin(), R.end(), EdgeLess());
+                    R.pop_back();
+                }
+            }
+        }
+    }
+    out_sorted.assign(R.begin(), R.end());
+    std::sort(out_sorted.begin(), out_sorted.end(), EdgeLess());
+}
+
+// select_neighbours (src/hnsw.rs:1299-1421).  cands_sorted ascending == pop order of the negated heap.
+void GraphBuilder::select_neighbours(const float* q, std::vector<Edge>& cands, size_t nb_asked, bool extend_asked,
+                                     unsigned layer, Tls& t, std::vector<Edge>& out) {
+    out.clear();
+    bool extend = false;
+    if (cands.size() <= nb_asked) {
+        if (!extend_asked) {
+            out = cands;
+            return;
+        }
+        extend = true;
+    }
+    if (extend) {
+        std::unordered_set<uint32_t> in_set;
+        for (const Edge& c : cands) in_set.insert(c.id);
+        std::vector<uint32_t> fresh;
+        size_t n0 = cands.size();
+        for (size_t i = 0; i < n0; ++i) {
+            read_list(cands[i].id, layer, t.tmp);
+            for (const Edge& e : t.tmp)
+                if (in_set.insert(e.id).second) fresh.push_back(e.id);
+        }
+        for (uint32_t id : fresh) cands.push_back({id, eval(q, vec(id))});
+        std::sort(cands.begin(), cands.end(), EdgeLess());
+    }
+    auto& discarded = t.discarded;
+    discarded.clear();
+    for (size_t i = 0; i < cands.size() && out.size() < nb_asked; ++i) {
+        const Edge& e = cands[i];
+        bool e_to_insert = true;
+        const float* ev = vec(e.id);
+        for (const Edge& dn : out)
+            if (eval(ev, vec(dn.id)) <= e.dist) {  // :1373-1375
+                e_to_insert = false;
+                break;
+            }
+        if (e_to_insert) out.push_back(e);
+        else if (p_.keep_pruned) discarded.push_back(e);
+    }
+    if (p_.keep_pruned)
+        for (size_t i = 0; i < discarded.size() && out.size() < nb_asked; ++i) out.push_back(discarded[i]);
+}
+
+// reverse_update_neighborhood_simple (src/hnsw.rs:1241-1289)
+void GraphBuilder::reverse_update(uint32_t id, Tls& t) {
+    Node& np = node(id);
+    const unsigned level = np.level;
+    for (int l = (int)level; l >= 0; --l) {
+        read_list(id, (unsigned)l, t.tmp);
+        for (const Edge& q : t.tmp) {
+            if (q.id == id) continue;
+            Node& qn = node(q.id);
+            SpinGuard g(qn.lock);
+            std::vector<Edge>& lst = qn.list(level);  // list at the NEW point's level (:1257)
+            bool already = false;
+            for (const Edge& old : lst)
+                if (old.id == id) { already = true; break; }
+            if (already) continue;
+            const size_t threshold = level > 0 ? p_.max_nb_connection : 2 * p_.max_nb_connection;
+            // push + sort_unstable + pop-if-over (:1268-1283): lists are always ascending, so this is
+            // an insertion after the last element <= the new distance
+            Edge ne{id, q.dist};
+            auto pos = std::upper_bound(lst.begin(), lst.end(), ne, EdgeLess());
+            lst.insert(pos, ne);
+            if (lst.size() > threshold) lst.pop_back();
+        }
+    }
+}
+
+// insert_slice (src/hnsw.rs:1077-1215); generate_new_point's bookkeeping was done by insert_batch.
+void GraphBuilder::insert_one(uint32_t id, Tls& t) {
+    Node& np = node(id);
+    const float* data = vec(id);
+    const unsigned level = np.level;
+    layer_inserted_[level].fetch_add(1, std::memory_order_acq_rel);  // points_by_layer[level].push (:516)
+    int64_t ep = entry_.load(std::memory_order_acquire);
+    if (ep < 0) {  // :1106-1109
+        std::lock_guard<std::mutex> g(entry_mutex_);
+        if (entry_.load() < 0) {
+            entry_level_.store((int)level);
+            entry_.store(id, std::memory_order_release);
+            return;
+        }
+        ep = entry_.load();
+    }
+    uint32_t enter = (uint32_t)ep;
+    const unsigned max_level_observed = node(enter).level;
+    float dist_to_entry = eval(data, vec(enter));  // :1110-1112
+    for (int l = (int)max_level_observed; l >= (int)level + 1; --l) {  // :1114-1155
+        search_layer(data, enter, 1, (unsigned)l, t, t.res);
+        if (!t.res.empty()) {
+            Edge hit = t.res[0];
+            {
+                SpinGuard g(np.lock);
+                std::vector<Edge>& lst = np.list((unsigned)l);
+                if (lst.size() < (size_t)(uint8_t)p_.max_nb_connection) lst.push_back(hit);  // :1140-1144
+            }
+            if (hit.dist < dist_to_entry) {
+                enter = hit.id;
+                dist_to_entry = hit.dist;
+            }
+        }
+    }
+    for (int l = (int)level; l >= 0; --l) {  // :1158-1205
+        search_layer(data, enter, p_.ef_construction, (unsigned)l, t, t.res);
+        if (!t.res.empty()) {
+            size_t nb_conn = l == 0 ? 2 * p_.max_nb_connection : p_.max_nb_connection;
+            bool extend_c = l == 0 ? p_.extend_candidates : false;
+            select_neighbours(data, t.res, nb_conn, extend_c, (unsigned)l, t, t.sel);
+            std::stable_sort(t.sel.begin(), t.sel.end(), EdgeLess());  // :1195
+            {
+                SpinGuard g(np.lock);
+                np.list((unsigned)l) = t.sel;  // :1197
+            }
+            if (!t.sel.empty()) enter = t.sel[0].id;  // :1201-1203
+        }
+    }
+    reverse_update(id, t);  // :1210
+    {                       // check_entry_point (src/hnsw.rs:534-557)
+        std::lock_guard<std::mutex> g(entry_mutex_);
+        if ((int)level > entry_level_.load()) {
+            entry_level_.store((int)level);
+            entry_.store(id, std::memory_order_release);
+        }
+    }
+}
+
+int GraphBuilder::insert_batch(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
+                               std::string& err) {
+    if (n == 0) return OK;
+    if (!data || d == 0) { err = "insert: null data or zero dimension"; return ERR_ARG; }
+    if (d_ == 0) d_ = d;
+    if (d != d_) { err = "insert: dimension differs from the index dimension"; return ERR_ARG; }
+    if (n_ + n >= NO_POINT) { err = "insert: too many points for 32-bit ids"; return ERR_ARG; }
+    if (p_.max_nb_connection > 256 || p_.max_nb_connection < 2) { err = "max_nb_connection must be in [2, 256]"; return ERR_ARG; }
+    // generate_new_point for the whole batch, in input order (src/hnsw.rs:503-531)
+    const uint64_t first = n_;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t id = (uint32_t)(first + i);
+        if ((id >> 16) >= chunks_.size()) {
+            chunks_.emplace_back(new Node[CHUNK]);
+            vecs_.emplace_back(new float[CHUNK * d_]);
+        }
+        Node& nd = node(id);
+        nd.level = (uint8_t)draw_level();
+        nd.rank = (int32_t)layer_rank_next_[nd.level]++;
+        nd.origin = ids ? ids[i] : (first + i);
+        std::memcpy(vecs_[id >> 16].get() + (uint64_t)(id & (CHUNK - 1)) * d_, data + i * d, d * sizeof(float));
+    }
+    n_ = first + n;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    uint64_t start = first;
+    Tls t0;
+    if (first == 0) {  // the very first point only becomes the entry point (:1096-1109)
+        insert_one(0, t0);
+        start = 1;
+    }
+    if (nthreads == 1 || n_ - start < 64) {
+        for (uint64_t i = start; i < n_; ++i) insert_one((uint32_t)i, t0);
+        return OK;
+    }
+    std::atomic<uint64_t> next{start};
+    auto worker = [&]() {
+        Tls t;
+        for (;;) {
+            uint64_t i = next.fetch_add(1);
+            if (i >= n_) break;
+            insert_one((uint32_t)i, t);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nthreads; ++k) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
+    return OK;
+}
+
+void GraphBuilder::finalize(FlatIndex& out) const {
+    out = FlatIndex();
+    out.format_version = 4;
+    out.dumpmode = 1;
+    out.max_nb_connection = p_.max_nb_connection;
+    out.level_scale = scale_;
+    out.nb_layer = (uint8_t)max_layer_;
+    out.ef_construction = p_.ef_construction;
+    out.dimension = d_;
+    out.dist = p_.dist;
+    out.distname = dist_type_name(p_.dist);
+    out.extend_candidates = p_.extend_candidates;
+    out.keep_pruned = p_.keep_pruned;
+    out.n = n_;
+    uint64_t acc = 0;
+    for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
+        out.layer_offset[l] = acc;
+        acc += layer_rank_next_[l];
+    }
+    out.layer_offset[NB_LAYER_MAX] = acc;
+    std::vector<uint32_t> flat_of(n_);
+    for (uint64_t i = 0; i < n_; ++i) {
+        const Node& nd = node((uint32_t)i);
+        flat_of[i] = (uint32_t)(out.layer_offset[nd.level] + (uint64_t)nd.rank);
+    }
+    out.origin_id.resize(n_);
+    out.vectors.resize(n_ * d_);
+    std::vector<uint32_t> id_of_flat(n_);
+    for (uint64_t i = 0; i < n_; ++i) id_of_flat[flat_of[i]] = (uint32_t)i;
+    out.nbr_ptr.assign(n_ * NB_LAYER_MAX + 1, 0);
+    uint64_t total = 0;
+    for (uint64_t f = 0; f < n_; ++f) {
+        const Node& nd = node(id_of_flat[f]);
+        for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
+            const std::vector<Edge>* lst = nd.list_if(l);
+            total += lst ? lst->size() : 0;
+            out.nbr_ptr[f * NB_LAYER_MAX + l + 1] = total;
+        }
+    }
+    out.nbr_flat.resize(total);
+    out.nbr_dist.resize(total);
+    for (uint64_t f = 0; f < n_; ++f) {
+        uint32_t id = id_of_flat[f];
+        const Node& nd = node(id);
+        out.origin_id[f] = nd.origin;
+        std::memcpy(out.vectors.data() + f * d_, vec(id), d_ * sizeof(float));
+        for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
+            const std::vector<Edge>* lst = nd.list_if(l);
+            if (!lst) continue;
+            uint64_t b = out.nbr_ptr[f * NB_LAYER_MAX + l];
+            for (size_t j = 0; j < lst->size(); ++j) {
+                out.nbr_flat[b + j] = flat_of[(*lst)[j].id];
+                out.nbr_dist[b + j] = (*lst)[j].dist;
+            }
+        }
+    }
+    int64_t ep = entry_.load();
+    out.entry_flat = ep < 0 ? NO_POINT : flat_of[ep];
+}
+
+int build_index(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, const BuildParams& p, FlatIndex& out,
+                std::string& err) {
+    GraphBuilder b(p);
+    int rc = b.insert_batch(data, n, d, ids, p.nthreads, err);
+    if (rc != OK) return rc;
+    b.finalize(out);
+    return OK;
+}
+
+}  // namespace hnswgpu

@@ -1,0 +1,81 @@
+// builder.hpp -- host-side graph construction on flat storage.
+//
+// Restates Hnsw::insert_slice / parallel_insert (src/hnsw.rs:1077-1238), select_neighbours
+// (:1299-1421) and reverse_update_neighborhood_simple (:1241-1289) on arrays indexed by
+// insertion order instead of the reference's Arc<Point> web.  The GPU search path reads the
+// result through FlatIndex; construction itself runs on the host cores (worker threads pull
+// points from an atomic counter, per-point spin locks stand in for the per-point RwLocks).
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "flat_index.hpp"
+
+namespace hnswgpu {
+
+struct BuildParams {
+    uint64_t max_nb_connection = 16;
+    uint64_t ef_construction = 200;
+    uint64_t max_layer = 16;
+    int dist = DIST_L2;
+    double level_scale_factor = 1.0;
+    bool extend_candidates = false;
+    bool keep_pruned = false;
+    int nthreads = 0;            // 1 = serial (deterministic), 0 = hardware_concurrency
+    bool fast_arithmetic = false;  // false: reference-order scalar sums
+};
+
+struct Edge {
+    uint32_t id;  // builder id = insertion order
+    float dist;
+};
+
+class GraphBuilder {
+public:
+    explicit GraphBuilder(const BuildParams& p);
+    ~GraphBuilder();
+    // insert n points (row-major n x d).  ids == nullptr: origin ids continue from nb_point().
+    int insert_batch(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads, std::string& err);
+    uint64_t nb_point() const { return n_; }
+    uint64_t dimension() const { return d_; }
+    const BuildParams& params() const { return p_; }
+    // flatten into dump order
+    void finalize(FlatIndex& out) const;
+
+private:
+    struct Node;
+    struct Tls;
+    static constexpr uint64_t CHUNK = 1u << 16;
+    Node& node(uint32_t id) const;
+    const float* vec(uint32_t id) const { return vecs_[id >> 16].get() + (uint64_t)(id & (CHUNK - 1)) * d_; }
+    float eval(const float* a, const float* b) const;
+    size_t draw_level();
+    void insert_one(uint32_t id, Tls& t);
+    void search_layer(const float* q, uint32_t entry, size_t ef, unsigned layer, Tls& t, std::vector<Edge>& out_sorted);
+    void select_neighbours(const float* q, std::vector<Edge>& cands_sorted, size_t nb_asked, bool extend_asked,
+                           unsigned layer, Tls& t, std::vector<Edge>& out);
+    void reverse_update(uint32_t id, Tls& t);
+    void read_list(uint32_t id, unsigned layer, std::vector<Edge>& out) const;
+
+    BuildParams p_;
+    uint64_t n_ = 0, d_ = 0;
+    unsigned max_layer_;
+    double scale_;
+    uint64_t rng_state_ = 397;
+    mutable std::vector<std::unique_ptr<Node[]>> chunks_;
+    std::vector<std::unique_ptr<float[]>> vecs_;
+    std::array<std::atomic<uint64_t>, NB_LAYER_MAX> layer_inserted_{};  // points_by_layer[l].len() as seen by searches
+    std::array<uint64_t, NB_LAYER_MAX> layer_rank_next_{};              // rank allocator (input order)
+    std::mutex entry_mutex_;
+    std::atomic<int64_t> entry_{-1};
+    std::atomic<int> entry_level_{-1};
+};
+
+// convenience: Hnsw::new + parallel_insert of a whole data set, flattened
+int build_index(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, const BuildParams& p, FlatIndex& out,
+                std::string& err);
+
+}  // namespace hnswgpu

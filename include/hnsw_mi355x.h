@@ -1,0 +1,215 @@
+/* hnsw_mi355x.h -- C ABI of libhnsw_mi355x.so
+ *
+ * MI355X-native drop-in for ONE hot path of the Rust crate hnsw_rs 0.3.4
+ * (jean-pierreBoth/hnswlib-rs): the batched k-NN search
+ *   AnnT::parallel_search_neighbours          src/api.rs:58-65
+ *   -> Hnsw::parallel_search                  src/hnsw.rs:1612-1635
+ *   -> Hnsw::search_filter(filter = None)     src/hnsw.rs:1487-1580
+ *   -> Hnsw::search_layer                     src/hnsw.rs:922-1064
+ *   -> Distance<f32>::eval (DistL2/DistCosine/DistDot/DistL1, crate anndists 0.1)
+ * together with the hnswio dump format on either side of it (src/hnswio.rs).
+ *
+ * Two groups of entry points:
+ *   (1) hnswgpu_*  : the thin ABI a Rust `impl AnnT` wrapper (or any host) binds; flat
+ *                    row-major matrices in, flat arrays out, integer status codes.
+ *   (2) the reference's own f32 C symbols (src/libext.rs), name- and layout-compatible,
+ *                    implemented on top of (1) -- existing C / Julia callers relink as is.
+ *
+ * All pointers are plain host pointers unless the name says `_device`.  No function aborts
+ * the process (the reference calls process::exit / panics): failures
+ * return a status / NULL and hnswgpu_last_error() explains.
+ * The search entry points REQUIRE a gfx950 device: there is no CPU fallback.
+ */
+#ifndef HNSW_MI355X_H
+#define HNSW_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status codes ------- */
+enum {
+    HNSWGPU_OK = 0,
+    HNSWGPU_ERR_ARG = 1,      /* bad argument (null, dimension mismatch, ...)             */
+    HNSWGPU_ERR_IO = 2,       /* cannot open / read / write a dump file                   */
+    HNSWGPU_ERR_FORMAT = 3,   /* bad magic, truncated file, incoherent ids                */
+    HNSWGPU_ERR_DISTANCE = 4, /* dump's distance name differs from the one asked          */
+    HNSWGPU_ERR_TYPE = 5,     /* dump's element type is not "f32"                         */
+    HNSWGPU_ERR_DEVICE = 6,   /* HIP error, or no gfx950 device / index not uploaded      */
+    HNSWGPU_ERR_EMPTY = 7     /* operation needs a non-empty index                        */
+};
+
+/* metric selector == short type name of the anndists distance */
+enum {
+    HNSWGPU_DIST_L2 = 0,     /* anndists::dist::distances::DistL2     sqrt(sum (a-b)^2)   */
+    HNSWGPU_DIST_COSINE = 1, /* ...::DistCosine   1 - a.b/sqrt(|a|^2 |b|^2), f64 sums     */
+    HNSWGPU_DIST_DOT = 2,    /* ...::DistDot      1 - a.b (inputs pre-normalised)         */
+    HNSWGPU_DIST_L1 = 3      /* ...::DistL1       sum |a-b|                               */
+};
+
+typedef struct hnswgpu_index hnswgpu_index; /* opaque: flat host graph + its HBM replica  */
+
+/* Thread-local message for the last failing call on this thread. */
+const char* hnswgpu_last_error(void);
+
+/* ---------------------------------------------------------------- load / dump -------- */
+/* HnswIo::new(dir, basename) + load_hnsw::<f32, D>()        src/hnswio.rs:317, :431-524
+ * `dist` = HNSWGPU_DIST_* the caller asks for (checked against the dump's distname by the
+ * short-name rule of src/hnswio.rs:473-490), or -1 to accept whatever the dump says.     */
+int hnswgpu_load_dump(const char* dir, const char* basename, int dist, hnswgpu_index** out);
+
+/* AnnT::file_dump(path, basename) in DumpMode::Full           src/api.rs:70-93,
+ * src/hnswio.rs:1355-1387.  Overwrites existing files (no unique-name logic).            */
+int hnswgpu_file_dump(const hnswgpu_index* idx, const char* dir, const char* basename);
+
+void hnswgpu_free_index(hnswgpu_index* idx);
+
+/* Description of a dump (load_description, src/hnswio.rs:937-1042).                       */
+typedef struct {
+    uint32_t format_version; /* 2, 3 or 4 (from the magic)                                */
+    uint8_t dumpmode;        /* 1 = Full                                                  */
+    uint8_t max_nb_connection;
+    uint8_t nb_layer;
+    double level_scale;
+    uint64_t ef_construction;
+    uint64_t nb_point;
+    uint64_t dimension;
+    char distname[260];
+    char t_name[260];
+} hnswgpu_description;
+int hnswgpu_load_description(const char* graph_file_path, hnswgpu_description* out);
+int hnswgpu_get_description(const hnswgpu_index* idx, hnswgpu_description* out);
+
+/* ---------------------------------------------------------------- construction ------- */
+/* Hnsw::<f32, D>::new(max_nb_connection, max_elements, max_layer, ef_construction, D)
+ * + (parallel_)insert of n points (src/hnsw.rs:771, :1077-1215, :1224-1238).  Host (CPU)
+ * construction; levels come from the documented SplitMix64(397) stream.   */
+typedef struct {
+    uint64_t max_nb_connection; /* M; layer-0 lists hold up to 2M                         */
+    uint64_t ef_construction;
+    uint64_t max_layer;         /* clamped to 16; must be 16 for the index to be dumpable */
+    int dist;                   /* HNSWGPU_DIST_*                                         */
+    double level_scale_factor;  /* modify_level_scale(), in [0.2, 1]; 1.0 = default       */
+    int extend_candidates;      /* set_extend_candidates()                                */
+    int keep_pruned;            /* set_keeping_pruned()                                   */
+    int nthreads;               /* 1 = serial insert (deterministic); 0 = all host cores  */
+    int fast_arithmetic;        /* 0: reference-order scalar sums; 1: 8-lane SIMD sums
+                                   (the crate's `simdeez_f` build order)                  */
+} hnswgpu_build_params;
+int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids /* NULL: 0..n-1 */,
+                  const hnswgpu_build_params* params, hnswgpu_index** out);
+
+/* ---------------------------------------------------------------- inspection --------- */
+uint64_t hnswgpu_nb_point(const hnswgpu_index* idx);
+uint64_t hnswgpu_dimension(const hnswgpu_index* idx);
+int hnswgpu_dist(const hnswgpu_index* idx);
+uint64_t hnswgpu_layer_nb_point(const hnswgpu_index* idx, unsigned layer);
+int hnswgpu_max_level_observed(const hnswgpu_index* idx);
+/* entry point as (origin_id, layer, rank); returns HNSWGPU_ERR_EMPTY on an empty index    */
+int hnswgpu_entry_point(const hnswgpu_index* idx, uint64_t* origin_id, uint8_t* layer, int32_t* rank);
+/* neighbour list of point (layer, rank) at layer `l`: fills up to cap entries, returns the
+ * list length (or -1).  Order = stored order (ascending stored distance).                 */
+int64_t hnswgpu_neighbours(const hnswgpu_index* idx, unsigned layer, int32_t rank, unsigned l, uint64_t cap,
+                           uint64_t* origin_ids, uint8_t* layers, int32_t* ranks, float* dists);
+
+/* ---------------------------------------------------------------- HBM replica -------- */
+/* Copies vectors (rows padded to 128-byte lines) and neighbour lists into the HBM of HIP
+ * device `device` (one process per GPU: call once per process).  Idempotent.              */
+int hnswgpu_upload(hnswgpu_index* idx, int device);
+int hnswgpu_device_count(void);
+
+/* ---------------------------------------------------------------- search ------------- */
+/* Hnsw::parallel_search(datas, knbn, ef) for a flat nq x d row-major query matrix
+ * (src/hnsw.rs:1612-1635).  Row i of the outputs holds out_counts[i] <= k valid entries in
+ * ascending distance: Neighbour{d_id, distance, p_id(layer, rank)} (src/hnsw.rs:98-107).
+ * out_layer / out_rank may be NULL.  Host buffers; includes H2D/D2H copies.               */
+int hnswgpu_search_batch(const hnswgpu_index* idx, const float* queries, uint64_t nq, uint64_t d, uint64_t k,
+                         uint64_t ef, uint64_t* out_ids, float* out_dists, uint8_t* out_layer, int32_t* out_rank,
+                         uint32_t* out_counts);
+
+/* Same with every buffer already resident in HBM (device pointers), launched on HIP stream
+ * `stream` (hipStream_t as void*; NULL = default stream).  Synchronises `stream` once
+ * before returning (the visited-set overflow check needs one 4-byte read-back).
+ * d_stats may be NULL, else uint32[nq*4] = {n_dist, n_expand, n_ids_read, status} per query. */
+int hnswgpu_search_batch_device(const hnswgpu_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                                uint64_t k, uint64_t ef, uint64_t* d_out_ids, float* d_out_dists,
+                                uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
+                                uint32_t* d_stats, void* stream);
+
+/* Timing of the kernels of the last search call on this index, measured with HIP events on
+ * the launch stream: total milliseconds and number of launches (retries included).        */
+int hnswgpu_last_kernel_ms(const hnswgpu_index* idx, double* ms, uint32_t* launches);
+
+/* Distance<f32>::eval evaluated ON THE DEVICE for n pairs (a[i], b[i]) of dimension d, in
+ * the same arithmetic as the search kernel (host buffers).  For arithmetic parity tests.  */
+int hnswgpu_eval_distances(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out);
+
+/* =======================================================================================
+ * (2) The reference's own C ABI for f32 (src/libext.rs), same names and struct layouts.
+ * ======================================================================================= */
+typedef struct HnswIo HnswIo;         /* src/hnswio.rs:300-310 (opaque)                   */
+typedef struct HnswApif32 HnswApif32; /* src/libext.rs:106 (opaque)                        */
+
+typedef struct { /* src/libext.rs:64-71 */
+    size_t id;
+    float d;
+} Neighbour_api;
+typedef struct { /* src/libext.rs:82-87 */
+    int64_t nbgh;
+    const Neighbour_api* neighbours;
+} Neighbourhood_api;
+typedef struct { /* Vec_api<Neighbourhood_api>, src/libext.rs:58-62 */
+    int64_t len;
+    const Neighbourhood_api* ptr;
+} Vec_api_Neighbourhood;
+typedef struct { /* src/libext.rs:1121-1141 */
+    uint8_t dumpmode;
+    uint8_t max_nb_connection;
+    uint8_t nb_layer;
+    size_t ef;
+    size_t nb_point;
+    size_t data_dimension;
+    size_t distname_len;
+    const uint8_t* distname;
+    size_t t_name_len;
+    const uint8_t* t_name;
+} DescriptionFFI;
+
+const HnswIo* get_hnswio(uint64_t flen, const uint8_t* name);                      /* :28-33   */
+const HnswApif32* load_hnswdump_f32_DistL1(HnswIo* hnswio);                        /* :310-315 */
+const HnswApif32* load_hnswdump_f32_DistL2(HnswIo* hnswio);                        /* :316-321 */
+const HnswApif32* load_hnswdump_f32_DistCosine(HnswIo* hnswio);                    /* :322-327 */
+const HnswApif32* load_hnswdump_f32_DistDot(HnswIo* hnswio);                       /* :328-333 */
+const HnswApif32* init_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namelen,
+                                const uint8_t* cdistname);                         /* :458-523 */
+const HnswApif32* new_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namelen, const uint8_t* cdistname,
+                               size_t max_elements, size_t max_layer);             /* :532-580 */
+void insert_f32(HnswApif32* hnsw_api, size_t len, const float* data, size_t id);   /* :661-678 */
+void parallel_insert_f32(HnswApif32* hnsw_api, size_t nb_vec, size_t vec_len, const float** datas,
+                         const size_t* ids);                                       /* :683-723 */
+const Neighbourhood_api* search_neighbours_f32(const HnswApif32* hnsw_api, size_t len, const float* data,
+                                               size_t knbn, size_t ef_search);     /* :728-767 */
+const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* hnsw_api, size_t nb_vec,
+                                                            int64_t vec_len, const float** data, size_t knbn,
+                                                            size_t ef_search);     /* :205-254 */
+int64_t file_dump_f32(const HnswApif32* hnsw_api, size_t namelen, const uint8_t* filename); /* :257-275 */
+void drop_hnsw_f32(const HnswApif32* p);                                           /* :626-630 */
+const DescriptionFFI* load_hnsw_description(size_t flen, const uint8_t* name);     /* :1171-1232 */
+void init_rust_log(void);                                                          /* :1238-1240 (no-op) */
+
+/* The reference leaks every result buffer to the caller and exports no free function
+ * (SURVEY.md 8b "Ownership").  These are additions.                                       */
+void hnswgpu_free_neighbourhood(const Neighbourhood_api* p);
+void hnswgpu_free_neighbourhood_vec(const Vec_api_Neighbourhood* p);
+void hnswgpu_free_hnswio(const HnswIo* p);
+void hnswgpu_free_description(const DescriptionFFI* p);
+/* access the thin-ABI handle behind a reference-style handle (NULL until built/loaded)    */
+hnswgpu_index* hnswgpu_from_api(const HnswApif32* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSW_MI355X_H */

@@ -1,0 +1,122 @@
+"""GPU parity tests: the HIP search path (through the C ABI) against the CPU oracle, same graph,
+same seeded inputs.  The bar: ids, p_ids, counts AND f32 distance bit patterns identical.
+
+Shapes follow BASELINE.json's configs at sizes the oracle finishes in seconds.
+"""
+import numpy as np
+import pytest
+
+from conftest import normalized, uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pair(native, oracle, tmp_path, n, d, m, efc, dist, seed, normalize=False, scale=None, tag="g"):
+    """Graph built by the ORACLE's restated insert, dumped in hnswio format, reloaded by the product."""
+    X = normalized(n, d, seed) if normalize else uniform(n, d, seed)
+    o = oracle.OracleHnsw(m, n, 16, efc, dist)
+    if scale is not None:
+        o.modify_level_scale(scale)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, tag)
+    h = native.HnswIo(tmp_path, tag).load_hnsw(dist)
+    h.upload(0)
+    return X, o, h
+
+
+def assert_same(res, ref):
+    assert np.array_equal(res.counts, ref.counts)
+    for i in range(len(ref.counts)):
+        c = int(ref.counts[i])
+        assert np.array_equal(res.ids[i, :c], ref.ids[i, :c]), f"ids differ for query {i}"
+        assert np.array_equal(res.dists[i, :c].view(np.uint32), ref.dists[i, :c].view(np.uint32)), f"distance bits differ for query {i}"
+        assert np.array_equal(res.layers[i, :c], ref.layers[i, :c])
+        assert np.array_equal(res.ranks[i, :c], ref.ranks[i, :c])
+
+
+CASES = [
+    # n, d, M, ef_c, dist, normalize, k, ef, nq      (BASELINE config it scales down)
+    (10000, 25, 15, 200, "DistL2", False, 10, 24, 1000),    # config 1 random.rs shape, full size
+    (5000, 128, 16, 200, "DistL2", False, 10, 64, 500),     # config 2 SIFT1M shape
+    (4000, 25, 24, 400, "DistCosine", False, 10, 128, 400),  # config 3 GloVe-25 shape, cosine
+    (4000, 25, 24, 400, "DistDot", True, 10, 128, 400),     # config 3, DistDot on normalised data
+    (1500, 784, 32, 400, "DistL2", False, 10, 200, 200),    # config 5 MNIST-784 shape
+    (3000, 10, 32, 400, "DistL1", False, 10, 20, 300),      # tests/serpar.rs shape (DistL1)
+]
+
+
+@pytest.mark.parametrize("n,d,m,efc,dist,normalize,k,ef,nq", CASES)
+def test_search_matches_oracle(native, oracle, tmp_path, n, d, m, efc, dist, normalize, k, ef, nq):
+    X, o, h = build_pair(native, oracle, tmp_path, n, d, m, efc, dist, seed=n + d, normalize=normalize)
+    Q = normalized(nq, d, 7) if normalize else uniform(nq, d, 7)
+    ref = o.parallel_search(Q, k, ef)
+    res = h.parallel_search_flat(Q, k, ef)
+    assert_same(res, ref)
+    # self queries: every point finds itself at distance 0 (src/hnswio.rs:1639-1640)
+    res_self = h.parallel_search_flat(X[:200], 1, ef)
+    if dist in ("DistL2", "DistL1"):
+        assert np.all(res_self.dists[:, 0] == 0.0)
+
+
+def test_k_larger_than_ef_and_short_answers(native, oracle, tmp_path):
+    X, o, h = build_pair(native, oracle, tmp_path, 300, 8, 8, 50, "DistL2", seed=3)
+    Q = uniform(50, 8, 11)
+    for k, ef in ((16, 4), (100, 10), (400, 3)):  # ef = max(ef, k); fewer than k answers when the graph is small
+        ref = o.parallel_search(Q, k, ef)
+        res = h.parallel_search_flat(Q, k, ef)
+        assert_same(res, ref)
+    assert res.counts.max() <= 300
+
+
+def test_sparse_single_point_index(native, oracle, tmp_path):
+    """src/hnsw.rs:1870-1881 test_sparse_search: one point (possibly drawn into a layer >= 1)."""
+    for seed in range(40):
+        X = uniform(1 + seed % 3, 4, 100 + seed)
+        o = oracle.OracleHnsw(8, 10, 16, 20, "DistL2")
+        for _ in range(seed):  # advance the level stream so the point lands in different layers
+            pass
+        o.insert_batch(X)
+        o.file_dump(tmp_path, "sp")
+        h = native.HnswIo(tmp_path, "sp").load_hnsw("DistL2")
+        res = h.parallel_search_flat(X[:1], 2, 10)
+        ref = o.parallel_search(X[:1], 2, 10)
+        assert_same(res, ref)
+        assert res.dists[0, 0] == 0.0
+
+
+def test_serial_equals_batched(native, oracle, tmp_path):
+    X, o, h = build_pair(native, oracle, tmp_path, 2000, 16, 12, 100, "DistL2", seed=5)
+    Q = uniform(64, 16, 13)
+    batched = h.parallel_search(Q, 8, 32)
+    for i in range(64):
+        assert h.search(Q[i], 8, 32) == batched[i]
+
+
+def test_device_distances_bit_exact(native, oracle):
+    rng = np.random.default_rng(0)
+    for dist in ("DistL2", "DistL1", "DistCosine", "DistDot"):
+        for d in (1, 3, 25, 128, 784):
+            a = (rng.random((256, d), dtype=np.float32) - 0.3) * 3
+            b = (rng.random((256, d), dtype=np.float32) - 0.3) * 3
+            if dist == "DistDot":
+                a, b = a * 0.05, b * 0.05
+            got = native.eval_distances(dist, a, b)
+            want = np.array([oracle.dist_eval(dist, a[i], b[i]) for i in range(256)], np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (dist, d)
+
+
+def test_sqrt_correctly_rounded(native):
+    """L2 of a 1-d vector = sqrt(x*x')... use d=1 with b=0: dist = sqrt(a^2) path exercises v_sqrt."""
+    rng = np.random.default_rng(1)
+    # choose a so that a*a is exactly representable: a = m * 2^e with 12-bit m
+    m = rng.integers(1, 4096, 4096).astype(np.float32)
+    e = rng.integers(-40, 40, 4096)
+    a = (m * np.exp2(e.astype(np.float32))).astype(np.float32)[:, None]
+    got = native.eval_distances("DistL2", a, np.zeros_like(a))
+    assert np.array_equal(got, np.abs(a[:, 0]))
+    # generic: two-term sums, compared with a correctly rounded host sqrt of the same f32 sum
+    x = rng.random((4096, 2), dtype=np.float32) * 100
+    s = (x[:, 0] * x[:, 0]).astype(np.float32)
+    s = (s + (x[:, 1] * x[:, 1]).astype(np.float32)).astype(np.float32)
+    got = native.eval_distances("DistL2", x, np.zeros_like(x))
+    assert np.array_equal(got, np.sqrt(s))
