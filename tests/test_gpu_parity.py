@@ -52,10 +52,14 @@ def test_search_matches_oracle(native, oracle, tmp_path, n, d, m, efc, dist, nor
     ref = o.parallel_search(Q, k, ef)
     res = h.parallel_search_flat(Q, k, ef)
     assert_same(res, ref)
-    # self queries: every point finds itself at distance 0 (src/hnswio.rs:1639-1640)
+    # self queries (tests/equality.rs counts how often a point finds itself; it is not always,
+    # on uniform high-d data): same answers as the oracle, and a found self is at distance exactly 0
     res_self = h.parallel_search_flat(X[:200], 1, ef)
+    assert_same(res_self, o.parallel_search(X[:200], 1, ef))
     if dist in ("DistL2", "DistL1"):
-        assert np.all(res_self.dists[:, 0] == 0.0)
+        found = res_self.ids[:, 0] == np.arange(200)
+        assert found.mean() > 0.8
+        assert np.all(res_self.dists[found, 0] == 0.0)
 
 
 def test_k_larger_than_ef_and_short_answers(native, oracle, tmp_path):
