@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""bench.py -- batched HNSW search (hnsw_rs `parallel_search_neighbours`) on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
+is launched by torch.distributed.run with one rank per GPU.  A *step* is one pass of the hot path
+over one batch of synthetic queries: greedy layer descent + layer-0 ef-expansion for every query
+of the batch, inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Workload at N=1 (BASELINE.json configs[1]): SIFT1M-shape synthetic, 1M x 128 f32, DistL2, M=16,
+ef_construction=200, ef=64, k=10, 10 000 queries.  For N>1 (configs[3]) the graph is replicated
+on every GPU and 12 500 queries per GPU are searched (100 000 over 8 GPUs), then all-gathered
+over RCCL; per-GPU work is fixed => "weak" scaling.
+
+What is untimed setup: synthetic data, graph construction on the host cores (product builder,
+cached as an hnswio dump under --cache-dir), dump reload, HBM upload, exact ground truth (torch
+GEMM on the GPU: harness, not hot path).  The CPU oracle is used ONLY in the cpu_baseline leg.
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+CONFIGS = {
+    # name: n, d, dist, M, ef_c, k, ef, nq (N=1), nq per GPU (N>1)
+    "sift1m": dict(n=1_000_000, d=128, dist="DistL2", M=16, efc=200, k=10, ef=64, nq=10_000, nq_multi=12_500,
+                   label="SIFT1M-shape synthetic 1Mx128 f32 L2 M=16 ef=64"),
+    "glove25": dict(n=1_200_000, d=25, dist="DistCosine", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000,
+                    label="GloVe-25-shape synthetic 1.2Mx25 f32 cosine M=24 ef=128"),
+    "mnist784": dict(n=60_000, d=784, dist="DistL2", M=32, efc=400, k=10, ef=200, nq=10_000, nq_multi=10_000,
+                     label="MNIST-784-shape synthetic 60kx784 f32 L2 M=32 ef=200"),
+    "random10k": dict(n=10_000, d=25, dist="DistL2", M=15, efc=200, k=10, ef=24, nq=1_000, nq_multi=1_000,
+                      label="random.rs shape 10kx25 f32 L2 M=15 ef=24"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def synth(n, d, seed, kind):
+    """Deterministic synthetic f32 vectors.  'uniform': iid U[0,1) (what every reference test uses);
+    'clustered': 1000-centre Gaussian mixture, sigma=0.1 (BASELINE.md distribution B)."""
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.random((n, d), dtype=np.float32)
+    centres = np.random.default_rng(0xC0FFEE).random((1000, d), dtype=np.float32)
+    out = np.empty((n, d), np.float32)
+    step = 1 << 18
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        c = rng.integers(0, 1000, e - s)
+        out[s:e] = centres[c] + 0.1 * rng.standard_normal((e - s, d), dtype=np.float32)
+    return out
+
+
+def ground_truth(torch, Xd, Qd, k, dist):
+    """Exact k-NN on the GPU: GEMM shortlist of 4k candidates, then f64 re-evaluation of the metric."""
+    nq = Qd.shape[0]
+    short = min(4 * k, Xd.shape[0])
+    ids = torch.empty((nq, k), dtype=torch.int64, device=Qd.device)
+    dd = torch.empty((nq, k), dtype=torch.float64, device=Qd.device)
+    xn = (Xd * Xd).sum(1)
+    for s in range(0, nq, 2048):
+        q = Qd[s:s + 2048]
+        if dist == "DistL2":
+            approx = xn[None, :] - 2.0 * (q @ Xd.T)
+        else:  # cosine / dot: larger similarity = smaller distance
+            approx = -(q @ Xd.T) / (xn.sqrt()[None, :] if dist == "DistCosine" else 1.0)
+        cand = approx.topk(short, dim=1, largest=False).indices
+        xc = Xd[cand].double()
+        qq = q.double()[:, None, :]
+        if dist == "DistL2":
+            ex = ((xc - qq) ** 2).sum(-1).sqrt()
+        elif dist == "DistCosine":
+            ex = 1.0 - (xc * qq).sum(-1) / ((xc * xc).sum(-1) * (qq * qq).sum(-1)).sqrt()
+        else:
+            ex = 1.0 - (xc * qq).sum(-1)
+        top = ex.topk(k, dim=1, largest=False)
+        ids[s:s + 2048] = torch.gather(cand, 1, top.indices)
+        dd[s:s + 2048] = top.values
+    return ids, dd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="sift1m", choices=sorted(CONFIGS))
+    ap.add_argument("--data", default="clustered", choices=["clustered", "uniform"])
+    ap.add_argument("--n", type=int, default=0, help="override the number of points (invalidates the headline config)")
+    ap.add_argument("--nq", type=int, default=0, help="override queries per GPU")
+    ap.add_argument("--ef", type=int, default=0)
+    ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
+    ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    args = ap.parse_args()
+
+    import torch  # first: the C-ABI library then binds to the HIP runtime torch already loaded
+    import hnsw_rs_amd as H
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_pg = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist_pg_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_pg_mod.init_process_group("nccl", timeout=datetime.timedelta(hours=2), device_id=dev)
+        dist_pg = dist_pg_mod
+
+    cfg = dict(CONFIGS[args.config])
+    if args.n:
+        cfg["n"] = args.n
+    if args.ef:
+        cfg["ef"] = args.ef
+    nq_local = args.nq or (cfg["nq"] if world == 1 else cfg["nq_multi"])
+    n, d, k, ef = cfg["n"], cfg["d"], cfg["k"], cfg["ef"]
+    H.build_native()
+    lib = H.lib()
+
+    # ---------------------------------------------------------------- index (cached hnswio dump)
+    key = hashlib.sha1(json.dumps([args.config, n, d, cfg["dist"], cfg["M"], cfg["efc"], args.data, "v1"]).encode()).hexdigest()[:12]
+    os.makedirs(args.cache_dir, exist_ok=True)
+    base = f"bench_{args.config}_{key}"
+    done_marker = os.path.join(args.cache_dir, base + ".done")
+    t_build = 0.0
+    if rank == 0 and not os.path.exists(done_marker):
+        log(f"building {cfg['label']} ({args.data} data) on the host cores ...")
+        X = synth(n, d, 0x5EED0001, args.data)
+        if cfg["dist"] == "DistDot":
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+        t0 = time.time()
+        hb = H.Hnsw(cfg["M"], n, 16, cfg["efc"], cfg["dist"])
+        hb.set_build_options(nthreads=args.build_threads, fast_arithmetic=True)
+        hb.parallel_insert(X)
+        t_build = time.time() - t0
+        log(f"built in {t_build:.1f} s ({n / t_build:.0f} points/s); dumping to {args.cache_dir}")
+        hb.file_dump(args.cache_dir, base)
+        del hb, X
+        with open(done_marker, "w") as f:
+            f.write(json.dumps({"build_s": t_build}))
+    while not os.path.exists(done_marker):  # other ranks: wait on the file system, not on a collective
+        time.sleep(1.0)
+    t0 = time.time()
+    index = H.HnswIo(args.cache_dir, base).load_hnsw(cfg["dist"])
+    index.upload(local_rank)
+    t_load = time.time() - t0
+    log(f"rank {rank}: dump reloaded + uploaded to HBM in {t_load:.1f} s; nb_point={index.get_nb_point()} "
+        f"max_level={index.get_max_level_observed()}")
+
+    # ---------------------------------------------------------------- queries (resident in HBM)
+    nq_total = nq_local * world
+    Q_all = synth(nq_total, d, 0x5EED0002, args.data)
+    if cfg["dist"] == "DistDot":
+        Q_all /= np.linalg.norm(Q_all, axis=1, keepdims=True)
+    Q = Q_all[rank * nq_local:(rank + 1) * nq_local]
+    Qd = torch.from_numpy(np.ascontiguousarray(Q)).to(dev)
+    out_ids = torch.zeros((nq_local, k), dtype=torch.int64, device=dev)
+    out_dists = torch.zeros((nq_local, k), dtype=torch.float32, device=dev)
+    out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
+    out_rank = torch.zeros((nq_local, k), dtype=torch.int32, device=dev)
+    out_counts = torch.zeros((nq_local,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((nq_local, 4), dtype=torch.int32, device=dev)
+    if world > 1:
+        gathered_ids = torch.empty((nq_total, k), dtype=torch.int64, device=dev)
+        gathered_dists = torch.empty((nq_total, k), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    kernel_ms = []
+
+    def step():
+        rc = lib.hnswgpu_search_batch_device(index.handle, Qd.data_ptr(), nq_local, d, k, ef, out_ids.data_ptr(),
+                                             out_dists.data_ptr(), out_layer.data_ptr(), out_rank.data_ptr(),
+                                             out_counts.data_ptr(), stats.data_ptr(), stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(H._native.last_error())
+        ms, _ = index.last_kernel_ms()  # HIP events on the launch stream, inside the library
+        kernel_ms.append(ms)
+        if world > 1:  # the only exchange on this path: gather of the answers (RCCL over xGMI)
+            dist_pg.all_gather_into_tensor(gathered_ids, out_ids)
+            dist_pg.all_gather_into_tensor(gathered_dists, out_dists)
+
+    def fence():
+        if world > 1:
+            dist_pg.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist_pg.all_reduce(t, op=dist_pg.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    qps = nq_total * args.steps / elapsed
+
+    # ---------------------------------------------------------------- recall vs exact brute force
+    res_ids = out_ids.cpu().numpy()
+    res_d = out_dists.cpu().numpy().astype(np.float64)
+    cnt = out_counts.cpu().numpy()
+    hit_id = 0
+    hit_dist = 0
+    if not args.no_recall:
+        Xd = torch.empty((n, d), dtype=torch.float32, device=dev)
+        # the same vectors the index was built from (regenerated, not read back through the API)
+        Xh = synth(n, d, 0x5EED0001, args.data)
+        if cfg["dist"] == "DistDot":
+            Xh /= np.linalg.norm(Xh, axis=1, keepdims=True)
+        Xd.copy_(torch.from_numpy(Xh))
+        del Xh
+        gt_ids, gt_d = ground_truth(torch, Xd, Qd, k, cfg["dist"])
+        del Xd
+        gt_ids_h, gt_d_h = gt_ids.cpu().numpy(), gt_d.cpu().numpy()
+        for i in range(nq_local):
+            c = int(cnt[i])
+            hit_id += len(set(res_ids[i, :c].tolist()) & set(gt_ids_h[i].tolist()))
+            hit_dist += int((res_d[i, :c] <= gt_d_h[i, k - 1] * (1 + 1e-6)).sum())  # examples/ann-sift1m...:172-186
+    recall = np.array([hit_id, hit_dist, nq_local * k], dtype=np.float64)
+    if world > 1:
+        t = torch.from_numpy(recall).to(dev)
+        dist_pg.all_reduce(t)
+        recall = t.cpu().numpy()
+    recall_id, recall_dist = recall[0] / recall[2], recall[1] / recall[2]
+
+    # ---------------------------------------------------------------- roofline of the search kernel
+    st = stats.cpu().numpy().astype(np.int64)
+    n_dist, n_expand, n_ids = int(st[:, 0].sum()), int(st[:, 1].sum()), int(st[:, 2].sum())
+    # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded
+    alg_bytes = n_dist * d * 4 + n_ids * 4 + n_expand * 8 + nq_local * (d * 4 + k * 12)
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("workload") == cfg["label"] and tj.get("data") == args.data:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    roofline = {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_ms, 4),
+                "launches_per_step": index.last_kernel_ms()[1],
+                "per_query": {"n_dist": n_dist / nq_local, "n_expand": n_expand / nq_local,
+                              "n_ids_read": n_ids / nq_local, "bytes": alg_bytes / nq_local,
+                              "n_dist_p50_p99_max": [int(np.percentile(st[:, 0], 50)), int(np.percentile(st[:, 0], 99)), int(st[:, 0].max())]}}
+
+    # ---------------------------------------------------------------- CPU baseline (oracle = checker)
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib
+        cores = os.cpu_count() or 1
+        t0 = time.time()
+        orc = oracle_lib.OracleHnsw.load(args.cache_dir, base, cfg["dist"])
+        log(f"oracle reloaded the same dump in {time.time() - t0:.1f} s; timing parallel_search on {cores} threads")
+        probe = min(nq_local, 256)
+        r = orc.parallel_search(Q[:probe], k, ef, cores)
+        rate = probe / max(r.elapsed_s, 1e-6)
+        sample = int(min(nq_local, max(probe, rate * args.cpu_seconds)))
+        r = orc.parallel_search(Q[:sample], k, ef, cores)
+        cpu_qps = sample / r.elapsed_s
+        same_ids = bool(np.array_equal(r.ids, res_ids[:sample].astype(np.uint64)) and np.array_equal(r.counts, cnt[:sample].astype(np.uint32)))
+        same_bits = bool(np.array_equal(r.dists.view(np.uint32), out_dists.cpu().numpy()[:sample].view(np.uint32)))
+        parity = {"queries_checked": sample, "ids_identical": same_ids, "f32_distance_bits_identical": same_bits}
+        cpu_baseline = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                        "sample": f"first {sample} of the same {nq_local} queries, same graph (reloaded from the same hnswio dump), "
+                                  f"oracle parallel_search with one thread per logical core, {r.elapsed_s:.1f} s"}
+        del orc
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec (+ recall@10), batched HNSW search",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": f"synthetic ({args.data}, seeds 0x5EED0001/0x5EED0002), graph built by the product builder",
+            "config": {"workload": cfg["label"], "n": n, "d": d, "distance": cfg["dist"], "M": cfg["M"],
+                       "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
+                       "queries_total": nq_total, "graph": "replicated per GPU", "exchange": "all_gather of answers (RCCL)" if world > 1 else "none"},
+            "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "parity_vs_oracle": parity,
+            "setup_s": {"build": round(t_build, 1), "load_upload": round(t_load, 1)},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist_pg.barrier()
+        dist_pg.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -32,8 +33,16 @@ namespace {
 
 constexpr uint32_t EXPANDED = 0x80000000u;  // flag bit on a result entry whose neighbour list was read
 constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
-constexpr int TABLE_LDS_HASH = 0;
-constexpr int TABLE_GLOBAL_BITMAP = 1;
+// visited-set representations (see visit_*)
+constexpr int TABLE_LDS_CELL16 = 0;
+constexpr int TABLE_LDS_CELL32 = 1;
+constexpr int TABLE_GLOBAL_BITMAP = 2;
+
+// LDS carve (bytes) in front of the visited table
+constexpr uint32_t TILE_ROWS = 16;                       // rows transposed per sub-batch
+constexpr uint32_t TILE_PITCH = TILE_ROWS + 1;           // float4 units; +1 keeps ds_write_b128 conflict-free
+constexpr uint32_t TILE_BYTES = 8 * TILE_PITCH * 16;     // 8 chunks of 16 B per row and pass
+constexpr uint32_t IDS_BYTES = 64 * 4;
 
 struct SearchArgs {
     const float* queries;   // [nq][row_stride], zero padded
@@ -41,7 +50,9 @@ struct SearchArgs {
     uint32_t nq;            // number of work items
     uint32_t k;
     uint32_t ef;            // already max(ef_arg, k)
-    uint32_t hash_bits;     // LDS table = 1 << hash_bits slots
+    uint32_t tbits;         // visited table = 1 << tbits cells
+    uint32_t idbits;        // ceil(log2(n))
+    uint32_t restbits;      // CELL16: idbits - tbits bits of the mixed id kept in the cell
     uint32_t* work_counter; // persistent-grid work queue head
     uint32_t* overflow_count;
     uint32_t* retry_out;    // queries whose visited table overflowed
@@ -63,83 +74,198 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
 }
 __device__ __forceinline__ uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 // ---------------------------------------------------------------------------------------
-// Distance<f32>::eval, one lane per (query, row) pair.  `q` is wave-uniform, `row` per lane.
-// Rows and queries are zero padded to row_stride, and x + 0 == x, so running over the padding
-// leaves every sum bit-identical to the d-term sum of the reference.
+// Distance<f32>::eval accumulators (anndists 0.1, scalar build).  add4 consumes four consecutive
+// vector elements IN ORDER; rows and queries are zero padded and x + 0 == x, so running over the
+// padding leaves every sum bit-identical to the reference's d-term left-to-right sum.
 // ---------------------------------------------------------------------------------------
 template <int METRIC>
-__device__ __forceinline__ float dist_row(const float4* __restrict__ q, const float4* __restrict__ row, uint32_t nchunk) {
-    if constexpr (METRIC == DIST_L2) {
-        float acc = 0.f;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            float4 r = row[c], s = q[c];
-            float t;
-            t = s.x - r.x; acc = acc + t * t;
-            t = s.y - r.y; acc = acc + t * t;
-            t = s.z - r.z; acc = acc + t * t;
-            t = s.w - r.w; acc = acc + t * t;
-        }
-        return __builtin_sqrtf(acc);
-    } else if constexpr (METRIC == DIST_L1) {
-        float acc = 0.f;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            float4 r = row[c], s = q[c];
-            acc = acc + fabsf(s.x - r.x);
-            acc = acc + fabsf(s.y - r.y);
-            acc = acc + fabsf(s.z - r.z);
-            acc = acc + fabsf(s.w - r.w);
-        }
-        return acc;
-    } else if constexpr (METRIC == DIST_DOT) {
-        float acc = 0.f;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            float4 r = row[c], s = q[c];
-            acc = acc + s.x * r.x;
-            acc = acc + s.y * r.y;
-            acc = acc + s.z * r.z;
-            acc = acc + s.w * r.w;
-        }
-        return fmaxf(1.f - acc, 0.f);
-    } else {  // DIST_COSINE: f32 products widened to f64, three f64 running sums
-        double s0 = 0., s1 = 0., s2 = 0.;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            float4 r = row[c], s = q[c];
-            s0 = s0 + (double)(s.x * r.x); s1 = s1 + (double)(s.x * s.x); s2 = s2 + (double)(r.x * r.x);
-            s0 = s0 + (double)(s.y * r.y); s1 = s1 + (double)(s.y * s.y); s2 = s2 + (double)(r.y * r.y);
-            s0 = s0 + (double)(s.z * r.z); s1 = s1 + (double)(s.z * s.z); s2 = s2 + (double)(r.z * r.z);
-            s0 = s0 + (double)(s.w * r.w); s1 = s1 + (double)(s.w * s.w); s2 = s2 + (double)(r.w * r.w);
-        }
+struct Acc;
+template <>
+struct Acc<DIST_L2> {
+    float a = 0.f;
+    __device__ __forceinline__ void add4(const float4 s, const float4 r) {
+        float t;
+        t = s.x - r.x; a = a + t * t;
+        t = s.y - r.y; a = a + t * t;
+        t = s.z - r.z; a = a + t * t;
+        t = s.w - r.w; a = a + t * t;
+    }
+    __device__ __forceinline__ float fin() const { return __builtin_sqrtf(a); }
+};
+template <>
+struct Acc<DIST_L1> {
+    float a = 0.f;
+    __device__ __forceinline__ void add4(const float4 s, const float4 r) {
+        a = a + fabsf(s.x - r.x);
+        a = a + fabsf(s.y - r.y);
+        a = a + fabsf(s.z - r.z);
+        a = a + fabsf(s.w - r.w);
+    }
+    __device__ __forceinline__ float fin() const { return a; }
+};
+template <>
+struct Acc<DIST_DOT> {
+    float a = 0.f;
+    __device__ __forceinline__ void add4(const float4 s, const float4 r) {
+        a = a + s.x * r.x;
+        a = a + s.y * r.y;
+        a = a + s.z * r.z;
+        a = a + s.w * r.w;
+    }
+    __device__ __forceinline__ float fin() const { return fmaxf(1.f - a, 0.f); }
+};
+template <>
+struct Acc<DIST_COSINE> {  // f32 products widened to f64, three f64 running sums
+    double s0 = 0., s1 = 0., s2 = 0.;
+    __device__ __forceinline__ void add4(const float4 s, const float4 r) {
+        s0 = s0 + (double)(s.x * r.x); s1 = s1 + (double)(s.x * s.x); s2 = s2 + (double)(r.x * r.x);
+        s0 = s0 + (double)(s.y * r.y); s1 = s1 + (double)(s.y * s.y); s2 = s2 + (double)(r.y * r.y);
+        s0 = s0 + (double)(s.z * r.z); s1 = s1 + (double)(s.z * s.z); s2 = s2 + (double)(r.z * r.z);
+        s0 = s0 + (double)(s.w * r.w); s1 = s1 + (double)(s.w * s.w); s2 = s2 + (double)(r.w * r.w);
+    }
+    __device__ __forceinline__ float fin() const {
         if (s1 > 0. && s2 > 0.) {
             double du = 1. - s0 / __builtin_sqrt(s1 * s2);
             return (float)fmax(du, 0.);
         }
         return 0.f;
     }
+};
+
+// one lane per pair, straight from global memory (used by the arithmetic test kernel)
+template <int METRIC>
+__device__ __forceinline__ float dist_row(const float4* __restrict__ q, const float4* __restrict__ row, uint32_t nchunk) {
+    Acc<METRIC> acc;
+    for (uint32_t c = 0; c < nchunk; ++c) acc.add4(q[c], row[c]);
+    return acc.fin();
 }
 
 // ---------------------------------------------------------------------------------------
-// Visited set (reference: hashbrown::HashMap<PointId, Arc<Point>>, src/hnsw.rs:955-956, :1016-1017).
-//   TABLE_LDS_HASH     : open-addressing table of flat ids in LDS, one table per wavefront.
-//   TABLE_GLOBAL_BITMAP: one bit per point in a per-workgroup slice of HBM (exact, cannot overflow);
-//                        the fallback when a query visits more points than the LDS table holds.
-// Both return true when `id` was NOT yet visited and mark it.
+// batch_dist: distances from the query (staged in LDS) to `nf` <= 64 rows whose flat ids sit in
+// ids_lds[0..nf).  Returns the distance to row r in LANE r.
+//
+// HBM side: every load instruction fetches 8 rows x one full 128-byte line (8 lanes x 16 B per
+// row), and all loads of up to 4 passes (16 rows x 512 B) are in flight before the first is used.
+// Arithmetic side: the reference sums each distance left to right over the vector index, which a
+// wave-wide reduction cannot reproduce bit for bit.  So the tile is transposed through LDS
+// (tile[chunk][row], pitch 17 float4: conflict-free for both the 8-lane ds_write_b128 groups and
+// the row-per-lane ds_read_b128) and lane r then walks row r sequentially -- one LANE per neighbour.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool visit_lds(uint32_t* tab, uint32_t bits, uint32_t id) {
-    const uint32_t mask = (1u << bits) - 1u;
-    uint32_t h = (id * 0x9E3779B1u) >> (32 - bits);
-    for (;;) {
-        uint32_t old = atomicCAS(&tab[h], EMPTY_SLOT, id);
-        if (old == EMPTY_SLOT) return true;
-        if (old == id) return false;
-        h = (h + 1) & mask;
+template <int METRIC, int G>
+__device__ __forceinline__ void pass_group(Acc<METRIC>& acc, const float* __restrict__ p0, const float* __restrict__ p1,
+                                           bool v0, bool v1, uint32_t pg, const float4* q_lds, float4* tile,
+                                           uint32_t lrow, uint32_t lchunk, uint32_t rr, bool mine) {
+    float4 b0[G], b1[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {  // every load of the group is in flight before the first use
+        b0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v0) b0[i] = *reinterpret_cast<const float4*>(p0 + (size_t)(pg + i) * 32u);
+        if (v1) b1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)(pg + i) * 32u);
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        __syncthreads();
+        if (v0) tile[lchunk * TILE_PITCH + lrow] = b0[i];
+        if (v1) tile[lchunk * TILE_PITCH + 8u + lrow] = b1[i];
+        __syncthreads();
+        if (mine) {
+            const float4* qp = q_lds + (size_t)(pg + i) * 8u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc.add4(qp[c], tile[(uint32_t)c * TILE_PITCH + rr]);
+        }
     }
 }
-__device__ __forceinline__ bool visit_bitmap(uint32_t* bm, uint32_t id) {
-    uint32_t bit = 1u << (id & 31);
-    uint32_t old = atomicOr(&bm[id >> 5], bit);
-    return (old & bit) == 0;
+
+template <int METRIC>
+__device__ __forceinline__ float batch_dist(const float* __restrict__ vec, uint32_t row_stride, const float4* q_lds,
+                                            float4* tile, const uint32_t* ids_lds, uint32_t nf, int lane) {
+    const uint32_t npass = row_stride >> 5;  // 32 floats (8 x 16 B) per row and pass
+    const uint32_t lrow = (uint32_t)lane >> 3, lchunk = (uint32_t)lane & 7u;
+    float result = INFINITY;
+    for (uint32_t s0 = 0; s0 < nf; s0 += TILE_ROWS) {
+        const uint32_t r0 = s0 + lrow, r1 = r0 + 8;
+        const bool v0 = r0 < nf, v1 = r1 < nf;
+        const float* p0 = vec + (size_t)ids_lds[v0 ? r0 : s0] * row_stride + lchunk * 4u;
+        const float* p1 = vec + (size_t)ids_lds[v1 ? r1 : s0] * row_stride + lchunk * 4u;
+        const bool mine = ((uint32_t)lane >> 4) == (s0 >> 4) && (uint32_t)lane < nf;
+        const uint32_t rr = (uint32_t)lane & 15u;
+        Acc<METRIC> acc;
+        uint32_t pg = 0;
+        for (; pg + 4 <= npass; pg += 4) pass_group<METRIC, 4>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
+        const uint32_t rem = npass - pg;
+        if (rem == 3) pass_group<METRIC, 3>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
+        else if (rem == 2) pass_group<METRIC, 2>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
+        else if (rem == 1) pass_group<METRIC, 1>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
+        if (mine) result = acc.fin();
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------------------
+// Visited set (reference: hashbrown::HashMap<PointId, Arc<Point>>, src/hnsw.rs:955-956, :1016-1017),
+// one per wavefront.  All three are EXACT (no false positives) and return true when `id` was not yet
+// visited, marking it.
+//   CELL16 : open addressing in LDS with 16-bit cells.  The id is passed through a bijection of
+//            [0, 2^idbits); its top tbits select the home cell, and the cell stores
+//            {valid, displacement from home, remaining restbits} -- enough to identify the id, at
+//            half the LDS of a table of full ids (LDS per wave is what bounds occupancy here).
+//   CELL32 : same with full 32-bit ids (large indexes where restbits would not fit).
+//   GLOBAL_BITMAP : one bit per point in a per-workgroup HBM slice; cannot overflow; last resort.
+// A lane that cannot place its id within the displacement budget reports overflow; the query is
+// then re-run from scratch with a larger representation (never a silent miss).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix_id(uint32_t id, uint32_t idbits) {
+    const uint32_t mask = idbits >= 32 ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    const uint32_t sh = (idbits + 1u) >> 1;
+    uint32_t h = (id * 0x9E3779B1u) & mask;
+    h ^= h >> sh;
+    h = (h * 0x85EBCA6Bu) & mask;
+    h ^= h >> sh;
+    return h;
+}
+// returns 0 = already visited, 1 = newly marked, 2 = no room
+__device__ __forceinline__ int visit_cell16(uint32_t* words, uint32_t tbits, uint32_t idbits, uint32_t restbits, uint32_t id) {
+    const uint32_t h = mix_id(id, idbits);
+    const uint32_t home = h >> restbits;
+    const uint32_t rest = h & ((1u << restbits) - 1u);
+    const uint32_t tmask = (1u << tbits) - 1u;
+    const uint32_t maxdisp = 1u << (15u - restbits);
+    for (uint32_t disp = 0; disp < maxdisp; ++disp) {
+        const uint32_t s = (home + disp) & tmask;
+        const uint32_t cell = 0x8000u | (disp << restbits) | rest;
+        const uint32_t sh = (s & 1u) * 16u;
+        for (;;) {
+            const uint32_t w = words[s >> 1];
+            const uint32_t half = (w >> sh) & 0xFFFFu;
+            if (half == 0u) {
+                if (atomicCAS(&words[s >> 1], w, w | (cell << sh)) == w) return 1;
+                continue;  // the other half (or this one) changed under us: look again
+            }
+            if (half == cell) return 0;
+            break;
+        }
+    }
+    return 2;
+}
+__device__ __forceinline__ int visit_cell32(uint32_t* tab, uint32_t tbits, uint32_t id) {
+    const uint32_t mask = (1u << tbits) - 1u;
+    uint32_t h = (id * 0x9E3779B1u) >> (32u - tbits);
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const uint32_t old = atomicCAS(&tab[h], EMPTY_SLOT, id);
+        if (old == EMPTY_SLOT) return 1;
+        if (old == id) return 0;
+        h = (h + 1u) & mask;
+    }
+    return 2;
+}
+__device__ __forceinline__ int visit_bitmap(uint32_t* bm, uint32_t id) {
+    const uint32_t bit = 1u << (id & 31u);
+    const uint32_t old = atomicOr(&bm[id >> 5], bit);
+    return (old & bit) == 0u ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -147,31 +273,35 @@ __device__ __forceinline__ bool visit_bitmap(uint32_t* bm, uint32_t id) {
 // Kept as ONE array sorted ascending by distance, entry j in VGPR slot j/64 of lane j%64, with an
 // EXPANDED flag: the candidates of the reference are exactly the not-yet-expanded members of R
 // (an entry evicted from R can only terminate the loop when popped: SURVEY.md section 3.1).
-// Insertion keeps arrival order among equal distances.
+// Insertion keeps arrival order among equal distances and reports whether an equal distance was
+// already present (a tie: the reference's answer then depends on its heaps' internal order).
 // ---------------------------------------------------------------------------------------
 template <int S>
-__device__ __forceinline__ void r_insert(float (&rd)[S], uint32_t (&ri)[S], uint32_t& len, uint32_t ef, float xd,
+__device__ __forceinline__ bool r_insert(float (&rd)[S], uint32_t (&ri)[S], uint32_t& len, uint32_t ef, float xd,
                                          uint32_t xi, int lane) {
     uint32_t pos = 0;
+    bool tie = false;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
+        const uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
         pos += popc64(__ballot(j < len && rd[s] <= xd));
+        tie = tie || (__ballot(j < len && rd[s] == xd) != 0ull);
     }
 #pragma unroll
     for (int s = S - 1; s >= 0; --s) {
         float pd = __shfl_up(rd[s], 1);
         uint32_t pi = (uint32_t)__shfl_up((int)ri[s], 1);
         if (s > 0) {
-            float wd = readlane_f(rd[s - 1], 63);
-            uint32_t wi = readlane_u(ri[s - 1], 63);
+            const float wd = readlane_f(rd[s - 1], 63);
+            const uint32_t wi = readlane_u(ri[s - 1], 63);
             if (lane == 0) { pd = wd; pi = wi; }
         }
-        uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
+        const uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
         if (j > pos) { rd[s] = pd; ri[s] = pi; }
         else if (j == pos) { rd[s] = xd; ri[s] = xi; }
     }
     len = len + 1 > ef ? ef : len + 1;  // the entry pushed past ef-1 is the evicted worst (src/hnsw.rs:1051-1053)
+    return tie;
 }
 template <int S>
 __device__ __forceinline__ float r_worst(const float (&rd)[S], uint32_t len) {
@@ -181,6 +311,26 @@ __device__ __forceinline__ float r_worst(const float (&rd)[S], uint32_t len) {
     for (int s = 0; s < S; ++s)
         if ((j >> 6) == (uint32_t)s) w = readlane_f(rd[s], (int)(j & 63));
     return w;
+}
+// nearest not-yet-expanded member of R: returns its index, or -1
+template <int S>
+__device__ __forceinline__ int r_next(const uint32_t (&ri)[S], uint32_t len, int lane) {
+    int j0 = -1;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
+        const unsigned long long m = __ballot(j < len && (ri[s] & EXPANDED) == 0u);
+        if (j0 < 0 && m != 0ull) j0 = s * 64 + ctz64(m);
+    }
+    return j0;
+}
+template <int S>
+__device__ __forceinline__ uint32_t r_id_at(const uint32_t (&ri)[S], int j) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        if ((j >> 6) == s) v = readlane_u(ri[s], j & 63);
+    return v & ~EXPANDED;
 }
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -192,15 +342,29 @@ __device__ __forceinline__ float wave_min(float v) {
 // ---------------------------------------------------------------------------------------
 // The search kernel: one wavefront (= one 64-thread workgroup) per query, persistent grid pulling
 // query indices from a global counter.
+// status per query: 0 ok, 1 visited-set overflow (re-run bigger), 2 ok but an exact distance tie
+// was met while inserting (answer is a valid search result; order among equals may differ from the
+// reference's heap order -- see DESIGN.md "ties").
 // ---------------------------------------------------------------------------------------
 template <int METRIC, int S, int TABLE>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_table[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4* tile = reinterpret_cast<float4*>(lds_raw);
+    uint32_t* ids_lds = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES);
+    float4* q_lds = reinterpret_cast<float4*>(lds_raw + TILE_BYTES + IDS_BYTES);
+    uint32_t* table = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES + IDS_BYTES + ix.row_stride * 4u);
     const int lane = (int)threadIdx.x;
-    const uint32_t nchunk = ix.row_stride >> 2;
-    const uint32_t table_slots = 1u << a.hash_bits;
-    const uint32_t table_limit = table_slots - (table_slots >> 2);  // stop inserting at 75 % load
+    const uint32_t table_cells = 1u << a.tbits;
+    const uint32_t table_words = TABLE == TABLE_LDS_CELL16 ? table_cells >> 1 : table_cells;
+    const uint32_t table_limit = table_cells - (table_cells >> 2);  // stop inserting at 75 % load
     uint32_t* bitmap = TABLE == TABLE_GLOBAL_BITMAP ? a.bitmap + (size_t)blockIdx.x * a.bitmap_words : nullptr;
+    const bool single_batch = ix.deg_stride <= 64u;
+
+    auto visit = [&](uint32_t id) -> int {
+        if constexpr (TABLE == TABLE_LDS_CELL16) return visit_cell16(table, a.tbits, a.idbits, a.restbits, id);
+        else if constexpr (TABLE == TABLE_LDS_CELL32) return visit_cell32(table, a.tbits, id);
+        else return visit_bitmap(bitmap, id);
+    };
 
     for (;;) {
         uint32_t wi = 0;
@@ -208,21 +372,29 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
         wi = readlane_u(wi, 0);
         if (wi >= a.nq) break;
         const uint32_t q = a.qlist ? a.qlist[wi] : wi;
-        const float4* qv = reinterpret_cast<const float4*>(a.queries + (size_t)q * ix.row_stride);
 
-        // ---- reset the visited set
-        if constexpr (TABLE == TABLE_LDS_HASH) {
-            for (uint32_t i = (uint32_t)lane; i < table_slots; i += 64) lds_table[i] = EMPTY_SLOT;
-        } else {
-            for (uint32_t i = (uint32_t)lane; i < a.bitmap_words; i += 64) bitmap[i] = 0u;
+        // ---- stage the query in LDS, reset the visited set
+        {
+            const float4* qg = reinterpret_cast<const float4*>(a.queries + (size_t)q * ix.row_stride);
+            for (uint32_t i = (uint32_t)lane; i < (ix.row_stride >> 2); i += 64) q_lds[i] = qg[i];
+            if constexpr (TABLE == TABLE_LDS_CELL16) {
+                for (uint32_t i = (uint32_t)lane; i < table_words; i += 64) table[i] = 0u;
+            } else if constexpr (TABLE == TABLE_LDS_CELL32) {
+                for (uint32_t i = (uint32_t)lane; i < table_words; i += 64) table[i] = EMPTY_SLOT;
+            } else {
+                for (uint32_t i = (uint32_t)lane; i < a.bitmap_words; i += 64) bitmap[i] = 0u;
+            }
         }
         __syncthreads();
 
         uint32_t n_dist = 0, n_expand = 0, n_ids = 0, status = 0;
+        bool tie = false;
 
         // ---- greedy descent: ONE scan of the pivot's list per layer (src/hnsw.rs:1506-1529)
         uint32_t pivot = ix.entry;
-        float dcur = dist_row<METRIC>(qv, reinterpret_cast<const float4*>(ix.vec + (size_t)pivot * ix.row_stride), nchunk);
+        if (lane == 0) ids_lds[0] = pivot;
+        __syncthreads();
+        float dcur = readlane_f(batch_dist<METRIC>(ix.vec, ix.row_stride, q_lds, tile, ids_lds, 1u, lane), 0);
         n_dist += 1;
         for (int layer = (int)ix.entry_level; layer >= 1; --layer) {
             uint32_t b = 0, e = 0;
@@ -239,9 +411,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
                 const uint32_t j = base + (uint32_t)lane;
                 const bool valid = j < e;
                 const uint32_t id = valid ? ix.up_ids[j] : 0u;
-                float dl = INFINITY;
-                if (valid) dl = dist_row<METRIC>(qv, reinterpret_cast<const float4*>(ix.vec + (size_t)id * ix.row_stride), nchunk);
-                n_dist += popc64(__ballot(valid));
+                const uint32_t nf = e - base < 64u ? e - base : 64u;
+                __syncthreads();
+                if (valid) ids_lds[lane] = id;
+                __syncthreads();
+                const float dl = batch_dist<METRIC>(ix.vec, ix.row_stride, q_lds, tile, ids_lds, nf, lane);  // INF in lanes >= nf
+                n_dist += nf;
                 const float m = wave_min(dl);
                 const unsigned long long eq = __ballot(valid && dl == m);
                 if (eq != 0ull && m < best) {  // strict '<': the first index wins ties (:1519)
@@ -263,70 +438,78 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
         uint32_t len = 1;
         if (lane == 0) { rd[0] = dcur; ri[0] = pivot; }  // dist_to_entry_point == eval(q, pivot) (:952)
         uint32_t n_visited = 1;
-        if (lane == 0) {
-            if constexpr (TABLE == TABLE_LDS_HASH) visit_lds(lds_table, a.hash_bits, pivot);
-            else visit_bitmap(bitmap, pivot);
-        }
+        if (lane == 0) (void)visit(pivot);
         __syncthreads();
 
+        uint32_t spec_for = EMPTY_SLOT, spec_ids = EMPTY_SLOT;  // prefetched id row of the likely next candidate
         for (;;) {
             // c = nearest unexpanded member of R (candidate_points.pop(), :971)
-            int cs = -1, cl = 0;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
-                const unsigned long long m = __ballot(j < len && (ri[s] & EXPANDED) == 0u);
-                if (cs < 0 && m != 0ull) { cs = s; cl = ctz64(m); }
-            }
-            if (cs < 0) break;  // every remaining candidate is farther than R's worst (:981-993)
-            uint32_t c = 0;
+            const int cj = r_next<S>(ri, len, lane);
+            if (cj < 0) break;  // every remaining candidate is farther than R's worst (:981-993)
+            const uint32_t c = r_id_at<S>(ri, cj);
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                if (s == cs) {
-                    c = readlane_u(ri[s], cl);
-                    if (lane == cl) ri[s] |= EXPANDED;
-                }
+                if ((cj >> 6) == s && lane == (cj & 63)) ri[s] |= EXPANDED;
             n_expand += 1;
             const uint32_t* nrow = ix.nbr0 + (size_t)c * ix.deg_stride;
-            for (uint32_t base = 0; base < ix.deg_stride; base += 64) {
-                const uint32_t j = base + (uint32_t)lane;
-                const uint32_t id = j < ix.deg_stride ? nrow[j] : EMPTY_SLOT;
+            const uint32_t nbatch = (ix.deg_stride + 63u) >> 6;
+            for (uint32_t bi = 0; bi < nbatch; ++bi) {
+                const uint32_t j = bi * 64u + (uint32_t)lane;
+                uint32_t id;
+                if (single_batch && spec_for == c) id = spec_ids;
+                else id = j < ix.deg_stride ? nrow[j] : EMPTY_SLOT;
+                if (single_batch) {
+                    // speculate on the next candidate: its id row is fetched while this one is processed
+                    const int nj = r_next<S>(ri, len, lane);
+                    if (nj >= 0) {
+                        spec_for = r_id_at<S>(ri, nj);
+                        spec_ids = (uint32_t)lane < ix.deg_stride ? ix.nbr0[(size_t)spec_for * ix.deg_stride + (uint32_t)lane] : EMPTY_SLOT;
+                    } else {
+                        spec_for = EMPTY_SLOT;
+                    }
+                }
                 const bool valid = id != EMPTY_SLOT;
                 const unsigned long long vm = __ballot(valid);
                 if (vm == 0ull) break;  // lists are padded at the end only
                 n_ids += popc64(vm);
-                if constexpr (TABLE == TABLE_LDS_HASH) {
+                if constexpr (TABLE != TABLE_GLOBAL_BITMAP) {
                     if (n_visited + 64 > table_limit) { status = 1; break; }
                 }
-                bool fresh = false;
-                if (valid) {
-                    if constexpr (TABLE == TABLE_LDS_HASH) fresh = visit_lds(lds_table, a.hash_bits, id);
-                    else fresh = visit_bitmap(bitmap, id);
-                }
+                int vr = 0;
+                if (valid) vr = visit(id);
+                if (__ballot(vr == 2) != 0ull) { status = 1; break; }
+                const bool fresh = vr == 1;
                 const unsigned long long fm = __ballot(fresh);
-                n_visited += popc64(fm);
-                n_dist += popc64(fm);
-                float de = INFINITY;
-                if (fresh) de = dist_row<METRIC>(qv, reinterpret_cast<const float4*>(ix.vec + (size_t)id * ix.row_stride), nchunk);
+                const uint32_t nf = popc64(fm);
+                if (nf == 0u) continue;
+                n_visited += nf;
+                n_dist += nf;
+                // compact the fresh ids in list order: rank r -> lane r
+                __syncthreads();
+                if (fresh) ids_lds[popc64(fm & lanemask_lt(lane))] = id;
+                __syncthreads();
+                const uint32_t idc = (uint32_t)lane < nf ? ids_lds[lane] : 0u;
+                const float de = batch_dist<METRIC>(ix.vec, ix.row_stride, q_lds, tile, ids_lds, nf, lane);
                 // accept rule applied sequentially in list order (:1028-1053)
                 float worst = r_worst<S>(rd, len);
-                unsigned long long cand = __ballot(fresh && (len < a.ef || de < worst));
+                unsigned long long cand = __ballot((uint32_t)lane < nf && (len < a.ef || de < worst));
                 while (cand != 0ull) {
                     const int jl = ctz64(cand);
                     cand &= cand - 1ull;
                     const float xd = readlane_f(de, jl);
                     if (xd < worst || len < a.ef) {
-                        const uint32_t xi = readlane_u(id, jl);
-                        r_insert<S>(rd, ri, len, a.ef, xd, xi, lane);
+                        const uint32_t xi = readlane_u(idc, jl);
+                        tie = r_insert<S>(rd, ri, len, a.ef, xd, xi, lane) || tie;
                         worst = r_worst<S>(rd, len);
                     }
                 }
             }
             if (status != 0) break;
         }
+        if (status == 0 && tie) status = 2;
 
         // ---- into_sorted_vec + truncate to min(knbn, ef, len) (:1544-1547, :1567-1578)
-        if (status == 0) {
+        if (status != 1) {
             const uint32_t cnt = len < a.k ? len : a.k;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -412,7 +595,11 @@ KernelFn pick_metric(int metric, int slots) {
     }
 }
 KernelFn pick_kernel(int metric, int slots, int table) {
-    return table == TABLE_LDS_HASH ? pick_metric<TABLE_LDS_HASH>(metric, slots) : pick_metric<TABLE_GLOBAL_BITMAP>(metric, slots);
+    switch (table) {
+        case TABLE_LDS_CELL16: return pick_metric<TABLE_LDS_CELL16>(metric, slots);
+        case TABLE_LDS_CELL32: return pick_metric<TABLE_LDS_CELL32>(metric, slots);
+        default: return pick_metric<TABLE_GLOBAL_BITMAP>(metric, slots);
+    }
 }
 
 uint32_t ceil_log2(uint64_t x) {
@@ -588,29 +775,50 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
                            static_cast<float*>(d_qpad_), (uint32_t)nq, v_.d, v_.row_stride);
     }
 
-    // first guess for the LDS table: 2x the expected number of visited points, in [2^10, 2^14] slots
-    const uint64_t expect = ef * std::min<uint64_t>(v_.deg_stride, 64) + 64;
-    uint32_t bits = std::min<uint32_t>(14u, std::max<uint32_t>(10u, ceil_log2(expect * 2)));
-    int table = TABLE_LDS_HASH;
+    // Visited-set sizing.  LDS per wavefront is what bounds occupancy, so start with a table sized for
+    // the typical query (~1.5 x ef x degree cells) and re-run the few queries that overflow it with a
+    // 4x table, then with the HBM bitmap (exact, cannot overflow).
+    const uint32_t idbits = std::max<uint32_t>(1u, ceil_log2(v_.n));
+    const uint64_t expect = ef * std::min<uint64_t>(v_.deg_stride, 64) * 3 / 2 + 64;
+    uint32_t tbits = std::min<uint32_t>(14u, std::max<uint32_t>(8u, ceil_log2(expect)));
+    if (const char* e = std::getenv("HNSWGPU_HASH_BITS")) {  // tuning / test hook: initial table size
+        int b = std::atoi(e);
+        if (b >= 6 && b <= 14) tbits = (uint32_t)b;
+    }
+    const size_t lds_fixed = TILE_BYTES + IDS_BYTES + (size_t)v_.row_stride * 4;
+    int table = TABLE_LDS_CELL16;
+    bool grown = false;
 
     uint32_t launches = 0;
     uint32_t work = (uint32_t)nq;
     const uint32_t* qlist = nullptr;
     int pingpong = 0;
     for (;;) {
+        SearchArgs a{};
+        size_t lds = lds_fixed;
+        if (table != TABLE_GLOBAL_BITMAP) {
+            uint32_t tb = std::min(tbits, idbits);  // a table with one cell per possible id never probes
+            if (idbits - tb <= 11u) {
+                table = TABLE_LDS_CELL16;
+                a.restbits = idbits - tb;
+                lds += (size_t)2 << tb;
+            } else {
+                table = TABLE_LDS_CELL32;
+                lds += (size_t)4 << tb;
+            }
+            a.tbits = tb;
+        }
+        a.idbits = idbits;
         KernelFn fn = pick_kernel(dist_, slots, table);
-        size_t lds = table == TABLE_LDS_HASH ? ((size_t)4 << bits) : 0;
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds));
         if (per_cu < 1) per_cu = 1;
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
-        SearchArgs a{};
         a.queries = static_cast<const float*>(d_qpad_);
         a.qlist = qlist;
         a.nq = work;
         a.k = (uint32_t)k;
         a.ef = (uint32_t)ef;
-        a.hash_bits = bits;
         a.work_counter = static_cast<uint32_t*>(d_ctrl_);
         a.overflow_count = static_cast<uint32_t*>(d_ctrl_) + 1;
         a.retry_out = static_cast<uint32_t*>(d_retry_[pingpong]);
@@ -640,13 +848,17 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         HIP_TRY(hipMemcpyAsync(ctrl, d_ctrl_, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (ctrl[1] == 0) break;
-        // some queries visited more points than the table holds: rerun only those, bigger table
+        // some queries visited more points than the table holds: rerun only those
         work = ctrl[1];
         qlist = static_cast<const uint32_t*>(d_retry_[pingpong]);
         pingpong ^= 1;
-        if (table == TABLE_LDS_HASH && bits < 14) bits = 14;
-        else if (table == TABLE_LDS_HASH) table = TABLE_GLOBAL_BITMAP;
-        else { err = "internal error: bitmap visited set reported an overflow"; return ERR_DEVICE; }
+        if (table == TABLE_GLOBAL_BITMAP) { err = "internal error: bitmap visited set reported an overflow"; return ERR_DEVICE; }
+        if (!grown && tbits < 14u) {
+            tbits = std::min<uint32_t>(14u, tbits + 2u);
+            grown = true;
+        } else {
+            table = TABLE_GLOBAL_BITMAP;
+        }
     }
     HIP_TRY(hipEventRecord((hipEvent_t)ev_stop_, stream));
     HIP_TRY(hipEventSynchronize((hipEvent_t)ev_stop_));

@@ -124,3 +124,18 @@ def test_sqrt_correctly_rounded(native):
     s = (s + (x[:, 1] * x[:, 1]).astype(np.float32)).astype(np.float32)
     got = native.eval_distances("DistL2", x, np.zeros_like(x))
     assert np.array_equal(got, np.sqrt(s))
+
+
+@pytest.mark.parametrize("bits", [6, 8, 10])
+def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, monkeypatch):
+    """A visited table far too small for the query must not change results: overflowing queries are
+    re-run with a 4x table and finally with the HBM bitmap (HNSWGPU_HASH_BITS is a test/tuning hook)."""
+    X, o, h = build_pair(native, oracle, tmp_path, 4000, 32, 16, 100, "DistL2", seed=21)
+    Q = uniform(300, 32, 22)
+    ref = o.parallel_search(Q, 10, 100)
+    monkeypatch.setenv("HNSWGPU_HASH_BITS", str(bits))
+    res = h.parallel_search_flat(Q, 10, 100)
+    assert_same(res, ref)
+    ms, launches = h.last_kernel_ms()
+    if bits <= 8:
+        assert launches >= 2
