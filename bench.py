@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
+    ap.add_argument("--dump-stats", default="", help="write the per-query kernel stats of the last step to this .npy")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -182,7 +183,7 @@ def main():
     out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
     out_rank = torch.zeros((nq_local, k), dtype=torch.int32, device=dev)
     out_counts = torch.zeros((nq_local,), dtype=torch.int32, device=dev)
-    stats = torch.zeros((nq_local, 4), dtype=torch.int32, device=dev)
+    stats = torch.zeros((nq_local, 8), dtype=torch.int32, device=dev)
     if world > 1:
         gathered_ids = torch.empty((nq_total, k), dtype=torch.int64, device=dev)
         gathered_dists = torch.empty((nq_total, k), dtype=torch.float32, device=dev)
@@ -253,6 +254,8 @@ def main():
 
     # ---------------------------------------------------------------- roofline of the search kernel
     st = stats.cpu().numpy().astype(np.int64)
+    if args.dump_stats and rank == 0:
+        np.save(args.dump_stats, st)
     n_dist, n_expand, n_ids = int(st[:, 0].sum()), int(st[:, 1].sum()), int(st[:, 2].sum())
     # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded
     alg_bytes = n_dist * d * 4 + n_ids * 4 + n_expand * 8 + nq_local * (d * 4 + k * 12)

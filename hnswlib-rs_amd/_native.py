@@ -10,6 +10,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhnsw_mi355x.so")
+# tuning hook: load a differently-built variant of the same library (kernel A/B runs in one process tree)
+LIB_OVERRIDE = os.environ.get("HNSW_MI355X_LIB")
 
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY = range(8)
 DIST = {"DistL2": 0, "DistCosine": 1, "DistDot": 2, "DistL1": 3}
@@ -118,11 +120,12 @@ def lib():
     """The loaded C-ABI library.  Raises if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_OVERRIDE or LIB_PATH
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with hnsw_rs_amd.build_native() "
+                f"{path} is missing: build it with hnsw_rs_amd.build_native() "
                 "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res

@@ -27,6 +27,24 @@
 
 #pragma clang fp contract(off)
 
+// tuning knobs (overridable with make TUNE=-D...)
+#ifndef HNSW_LB_WAVES
+#define HNSW_LB_WAVES 4   // __launch_bounds__ waves per SIMD: LDS already caps residency near 4
+#endif
+#ifndef HNSW_PHASE_TIMING
+#define HNSW_PHASE_TIMING 0  // 1: per-query cycle counts of the expansion phases go to stats[8..15] (profiling builds)
+#endif
+#if HNSW_PHASE_TIMING
+#define PH_T(var) const unsigned long long var = clock64()
+#define PH_ACC(idx, t0, t1) ph[idx] += (uint32_t)((t1) - (t0))
+#else
+#define PH_T(var)
+#define PH_ACC(idx, t0, t1)
+#endif
+#ifndef HNSW_ACC_SPLIT
+#define HNSW_ACC_SPLIT 0  // 1: all 32 squares first, then the add chain (needs 32 more VGPRs); 0: per element
+#endif
+
 namespace hnswgpu {
 
 namespace {
@@ -41,7 +59,7 @@ constexpr int TABLE_GLOBAL_BITMAP = 2;
 // LDS carve (bytes) in front of the visited table
 constexpr uint32_t TILE_ROWS = 16;                       // rows transposed per sub-batch
 constexpr uint32_t TILE_PITCH = TILE_ROWS + 1;           // float4 units; +1 keeps ds_write_b128 conflict-free
-constexpr uint32_t TILE_BYTES = 8 * TILE_PITCH * 16;     // 8 chunks of 16 B per row and pass
+constexpr uint32_t TILE_BYTES = 2 * 8 * TILE_PITCH * 16; // two buffers of 8 chunks x 16 B per row and pass
 constexpr uint32_t IDS_BYTES = 64 * 4;
 
 struct SearchArgs {
@@ -56,14 +74,15 @@ struct SearchArgs {
     uint32_t* work_counter; // persistent-grid work queue head
     uint32_t* overflow_count;
     uint32_t* retry_out;    // queries whose visited table overflowed
-    uint32_t* bitmap;       // TABLE_GLOBAL_BITMAP: [gridDim.x][bitmap_words]
+    uint32_t* bitmap;       // [bitmap_blocks][bitmap_words]: per-workgroup visited bitmaps in HBM
     uint32_t bitmap_words;
+    uint32_t bitmap_blocks; // workgroups with blockIdx.x < bitmap_blocks own a slice
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
     int32_t* out_rank;
     uint32_t* out_counts;
-    uint32_t* stats;        // [nq_total][4] = n_dist, n_expand, n_ids_read, status
+    uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used, 0
 };
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
@@ -93,6 +112,21 @@ struct Acc<DIST_L2> {
         t = s.z - r.z; a = a + t * t;
         t = s.w - r.w; a = a + t * t;
     }
+    // 8 consecutive float4 (32 elements): all differences and squares first (independent, packed
+    // math, full VALU rate), then the 32 dependent adds of the reference's left-to-right sum
+    __device__ __forceinline__ void add32(const float4 (&s)[8], const float4 (&r)[8]) {
+        float sq[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t;
+            t = s[c].x - r[c].x; sq[4 * c + 0] = t * t;
+            t = s[c].y - r[c].y; sq[4 * c + 1] = t * t;
+            t = s[c].z - r[c].z; sq[4 * c + 2] = t * t;
+            t = s[c].w - r[c].w; sq[4 * c + 3] = t * t;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a = a + sq[i];
+    }
     __device__ __forceinline__ float fin() const { return __builtin_sqrtf(a); }
 };
 template <>
@@ -103,6 +137,18 @@ struct Acc<DIST_L1> {
         a = a + fabsf(s.y - r.y);
         a = a + fabsf(s.z - r.z);
         a = a + fabsf(s.w - r.w);
+    }
+    __device__ __forceinline__ void add32(const float4 (&s)[8], const float4 (&r)[8]) {
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            v[4 * c + 0] = fabsf(s[c].x - r[c].x);
+            v[4 * c + 1] = fabsf(s[c].y - r[c].y);
+            v[4 * c + 2] = fabsf(s[c].z - r[c].z);
+            v[4 * c + 3] = fabsf(s[c].w - r[c].w);
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a = a + v[i];
     }
     __device__ __forceinline__ float fin() const { return a; }
 };
@@ -115,6 +161,18 @@ struct Acc<DIST_DOT> {
         a = a + s.z * r.z;
         a = a + s.w * r.w;
     }
+    __device__ __forceinline__ void add32(const float4 (&s)[8], const float4 (&r)[8]) {
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            v[4 * c + 0] = s[c].x * r[c].x;
+            v[4 * c + 1] = s[c].y * r[c].y;
+            v[4 * c + 2] = s[c].z * r[c].z;
+            v[4 * c + 3] = s[c].w * r[c].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a = a + v[i];
+    }
     __device__ __forceinline__ float fin() const { return fmaxf(1.f - a, 0.f); }
 };
 template <>
@@ -125,6 +183,10 @@ struct Acc<DIST_COSINE> {  // f32 products widened to f64, three f64 running sum
         s0 = s0 + (double)(s.y * r.y); s1 = s1 + (double)(s.y * s.y); s2 = s2 + (double)(r.y * r.y);
         s0 = s0 + (double)(s.z * r.z); s1 = s1 + (double)(s.z * s.z); s2 = s2 + (double)(r.z * r.z);
         s0 = s0 + (double)(s.w * r.w); s1 = s1 + (double)(s.w * s.w); s2 = s2 + (double)(r.w * r.w);
+    }
+    __device__ __forceinline__ void add32(const float4 (&s)[8], const float4 (&r)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) add4(s[c], r[c]);
     }
     __device__ __forceinline__ float fin() const {
         if (s1 > 0. && s2 > 0.) {
@@ -154,52 +216,93 @@ __device__ __forceinline__ float dist_row(const float4* __restrict__ q, const fl
 // (tile[chunk][row], pitch 17 float4: conflict-free for both the 8-lane ds_write_b128 groups and
 // the row-per-lane ds_read_b128) and lane r then walks row r sequentially -- one LANE per neighbour.
 // ---------------------------------------------------------------------------------------
+// Single-wavefront workgroups: LDS instructions of one wave execute in program order, so a
+// ds_write followed by a ds_read of another lane's data needs no s_barrier and no drained counter --
+// only a fence that keeps the compiler from reordering the two.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+// the query row is wave-uniform and read-only for the whole launch: constant address space =>
+// s_load_dwordx16 into SGPRs, consumed directly as VALU scalar operands (no VGPRs, no LDS)
+typedef __attribute__((address_space(4))) const v4f* qptr_t;
+
+// one pass = 32 consecutive elements of every row of the sub-batch
+__device__ __forceinline__ void tile_write(float4* buf, const float4 x0, const float4 x1, uint32_t lrow, uint32_t lchunk) {
+    buf[lchunk * TILE_PITCH + lrow] = x0;
+    buf[lchunk * TILE_PITCH + 8u + lrow] = x1;
+}
+template <int METRIC>
+__device__ __forceinline__ void pass_read_accumulate(Acc<METRIC>& acc, const float4* buf, uint32_t rr, uint32_t pass, qptr_t q) {
+    qptr_t qp = q + (size_t)pass * 8u;
+    float4 sv[8], rv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const v4f s = qp[c];
+        sv[c] = make_float4(s.x, s.y, s.z, s.w);
+        rv[c] = buf[(uint32_t)c * TILE_PITCH + rr];
+    }
+#if HNSW_ACC_SPLIT
+    acc.add32(sv, rv);
+#else
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc.add4(sv[c], rv[c]);
+#endif
+}
+
+// G passes (G x 16 rows x 128 B) are loaded before the first is consumed; the transposing tile is
+// double buffered so that the LDS write+read of pass i+1 overlaps the dependent add chain of pass i.
+// Named scalars on purpose: arrays of loads end up in scratch memory.
 template <int METRIC, int G>
 __device__ __forceinline__ void pass_group(Acc<METRIC>& acc, const float* __restrict__ p0, const float* __restrict__ p1,
-                                           bool v0, bool v1, uint32_t pg, const float4* q_lds, float4* tile,
-                                           uint32_t lrow, uint32_t lchunk, uint32_t rr, bool mine) {
-    float4 b0[G], b1[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) {  // every load of the group is in flight before the first use
-        b0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        b1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v0) b0[i] = *reinterpret_cast<const float4*>(p0 + (size_t)(pg + i) * 32u);
-        if (v1) b1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)(pg + i) * 32u);
-    }
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        __syncthreads();
-        if (v0) tile[lchunk * TILE_PITCH + lrow] = b0[i];
-        if (v1) tile[lchunk * TILE_PITCH + 8u + lrow] = b1[i];
-        __syncthreads();
-        if (mine) {
-            const float4* qp = q_lds + (size_t)(pg + i) * 8u;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc.add4(qp[c], tile[(uint32_t)c * TILE_PITCH + rr]);
-        }
-    }
+                                           uint32_t pg, qptr_t q, float4* tile, uint32_t lrow, uint32_t lchunk,
+                                           uint32_t rr, bool mine) {
+    const float4* a0 = reinterpret_cast<const float4*>(p0 + (size_t)pg * 32u);
+    const float4* a1 = reinterpret_cast<const float4*>(p1 + (size_t)pg * 32u);
+    float4 x00, x01, x10, x11, x20, x21, x30, x31;
+    x00 = a0[0]; x01 = a1[0];
+    if constexpr (G > 1) { x10 = a0[8]; x11 = a1[8]; }
+    if constexpr (G > 2) { x20 = a0[16]; x21 = a1[16]; }
+    if constexpr (G > 3) { x30 = a0[24]; x31 = a1[24]; }
+    float4* t0 = tile;
+    float4* t1 = tile + 8 * TILE_PITCH;
+    // pass i+1 is written into the other buffer BEFORE pass i is consumed (LDS ops of one wave run in
+    // program order, so no hazard: the reads of a buffer always precede its next overwrite)
+    wave_lds_fence();
+    tile_write(t0, x00, x01, lrow, lchunk);
+    if constexpr (G > 1) tile_write(t1, x10, x11, lrow, lchunk);
+    wave_lds_fence();
+    if (mine) pass_read_accumulate<METRIC>(acc, t0, rr, pg, q);
+    if constexpr (G > 2) { wave_lds_fence(); tile_write(t0, x20, x21, lrow, lchunk); wave_lds_fence(); }
+    if constexpr (G > 1) { if (mine) pass_read_accumulate<METRIC>(acc, t1, rr, pg + 1, q); }
+    if constexpr (G > 3) { wave_lds_fence(); tile_write(t1, x30, x31, lrow, lchunk); wave_lds_fence(); }
+    if constexpr (G > 2) { if (mine) pass_read_accumulate<METRIC>(acc, t0, rr, pg + 2, q); }
+    if constexpr (G > 3) { if (mine) pass_read_accumulate<METRIC>(acc, t1, rr, pg + 3, q); }
 }
 
 template <int METRIC>
-__device__ __forceinline__ float batch_dist(const float* __restrict__ vec, uint32_t row_stride, const float4* q_lds,
+__device__ __forceinline__ float batch_dist(const float* __restrict__ vec, uint32_t row_stride, qptr_t q,
                                             float4* tile, const uint32_t* ids_lds, uint32_t nf, int lane) {
     const uint32_t npass = row_stride >> 5;  // 32 floats (8 x 16 B) per row and pass
     const uint32_t lrow = (uint32_t)lane >> 3, lchunk = (uint32_t)lane & 7u;
     float result = INFINITY;
     for (uint32_t s0 = 0; s0 < nf; s0 += TILE_ROWS) {
+        // lanes past the last row re-read row s0 (same cache lines as the lanes that own it: free)
         const uint32_t r0 = s0 + lrow, r1 = r0 + 8;
-        const bool v0 = r0 < nf, v1 = r1 < nf;
-        const float* p0 = vec + (size_t)ids_lds[v0 ? r0 : s0] * row_stride + lchunk * 4u;
-        const float* p1 = vec + (size_t)ids_lds[v1 ? r1 : s0] * row_stride + lchunk * 4u;
+        const float* p0 = vec + (size_t)ids_lds[r0 < nf ? r0 : s0] * row_stride + lchunk * 4u;
+        const float* p1 = vec + (size_t)ids_lds[r1 < nf ? r1 : s0] * row_stride + lchunk * 4u;
         const bool mine = ((uint32_t)lane >> 4) == (s0 >> 4) && (uint32_t)lane < nf;
         const uint32_t rr = (uint32_t)lane & 15u;
         Acc<METRIC> acc;
         uint32_t pg = 0;
-        for (; pg + 4 <= npass; pg += 4) pass_group<METRIC, 4>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
+        for (; pg + 4 <= npass; pg += 4) pass_group<METRIC, 4>(acc, p0, p1, pg, q, tile, lrow, lchunk, rr, mine);
         const uint32_t rem = npass - pg;
-        if (rem == 3) pass_group<METRIC, 3>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
-        else if (rem == 2) pass_group<METRIC, 2>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
-        else if (rem == 1) pass_group<METRIC, 1>(acc, p0, p1, v0, v1, pg, q_lds, tile, lrow, lchunk, rr, mine);
+        if (rem == 3) pass_group<METRIC, 3>(acc, p0, p1, pg, q, tile, lrow, lchunk, rr, mine);
+        else if (rem == 2) pass_group<METRIC, 2>(acc, p0, p1, pg, q, tile, lrow, lchunk, rr, mine);
+        else if (rem == 1) pass_group<METRIC, 1>(acc, p0, p1, pg, q, tile, lrow, lchunk, rr, mine);
         if (mine) result = acc.fin();
     }
     return result;
@@ -227,27 +330,50 @@ __device__ __forceinline__ uint32_t mix_id(uint32_t id, uint32_t idbits) {
     h ^= h >> sh;
     return h;
 }
-// returns 0 = already visited, 1 = newly marked, 2 = no room
+// inverse of mix_id (each step is a bijection of [0, 2^idbits): odd multipliers have inverses mod 2^k,
+// and x ^= x >> s is an involution once 2s >= idbits)
+__device__ __forceinline__ uint32_t unmix_id(uint32_t h, uint32_t idbits) {
+    const uint32_t mask = idbits >= 32 ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    const uint32_t sh = (idbits + 1u) >> 1;
+    h ^= h >> sh;
+    h = (h * 0xA5CB9243u) & mask;  // 0x85EBCA6B^-1 mod 2^32
+    h ^= h >> sh;
+    h = (h * 0x0E8B2F51u) & mask;  // 0x9E3779B1^-1 mod 2^32
+    return h;
+}
+// returns 0 = already visited, 1 = newly marked, 2 = no room.
+// Linear probing, but a probe fetches the whole aligned 16-byte block (8 cells) with ONE ds_read_b128 and
+// scans it in registers: a wave waits for its slowest lane, and the dependent LDS round trips of that
+// lane were the cost of this function.
 __device__ __forceinline__ int visit_cell16(uint32_t* words, uint32_t tbits, uint32_t idbits, uint32_t restbits, uint32_t id) {
     const uint32_t h = mix_id(id, idbits);
     const uint32_t home = h >> restbits;
     const uint32_t rest = h & ((1u << restbits) - 1u);
     const uint32_t tmask = (1u << tbits) - 1u;
     const uint32_t maxdisp = 1u << (15u - restbits);
-    for (uint32_t disp = 0; disp < maxdisp; ++disp) {
-        const uint32_t s = (home + disp) & tmask;
-        const uint32_t cell = 0x8000u | (disp << restbits) | rest;
-        const uint32_t sh = (s & 1u) * 16u;
-        for (;;) {
-            const uint32_t w = words[s >> 1];
-            const uint32_t half = (w >> sh) & 0xFFFFu;
-            if (half == 0u) {
-                if (atomicCAS(&words[s >> 1], w, w | (cell << sh)) == w) return 1;
-                continue;  // the other half (or this one) changed under us: look again
+    const uint4* blocks = reinterpret_cast<const uint4*>(words);
+    uint32_t disp = 0;
+    while (disp < maxdisp) {
+        const uint32_t pos = (home + disp) & tmask;
+        const uint4 v = blocks[pos >> 3];
+        const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+        const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+        bool reread = false;
+        for (uint32_t j = pos & 7u; j < 8u; ++j, ++disp) {
+            if (disp >= maxdisp) return 2;
+            const uint32_t cellv = (uint32_t)(((j < 4u ? lo : hi) >> ((j & 3u) * 16u)) & 0xFFFFull);
+            const uint32_t expect = 0x8000u | (disp << restbits) | rest;
+            if (cellv == expect) return 0;
+            if (cellv == 0u) {
+                const uint32_t cell = (pos & ~7u) + j;          // (no wrap inside an aligned block)
+                const uint32_t w32 = j < 2u ? v.x : j < 4u ? v.y : j < 6u ? v.z : v.w;
+                const uint32_t sh = (j & 1u) * 16u;
+                if (atomicCAS(&words[cell >> 1], w32, w32 | (expect << sh)) == w32) return 1;
+                reread = true;  // this word changed under us (another lane): look at the block again
+                break;
             }
-            if (half == cell) return 0;
-            break;
         }
+        (void)reread;
     }
     return 2;
 }
@@ -289,13 +415,14 @@ __device__ __forceinline__ bool r_insert(float (&rd)[S], uint32_t (&ri)[S], uint
     }
 #pragma unroll
     for (int s = S - 1; s >= 0; --s) {
-        float pd = __shfl_up(rd[s], 1);
-        uint32_t pi = (uint32_t)__shfl_up((int)ri[s], 1);
+        // entry j-1 -> j: DPP wave_shr:1 inside a slot, lane 63 of the previous slot into lane 0
+        int od = __float_as_int(rd[s]), oi = (int)ri[s];
         if (s > 0) {
-            const float wd = readlane_f(rd[s - 1], 63);
-            const uint32_t wi = readlane_u(ri[s - 1], 63);
-            if (lane == 0) { pd = wd; pi = wi; }
+            od = __builtin_amdgcn_readlane(__float_as_int(rd[s - 1]), 63);
+            oi = __builtin_amdgcn_readlane((int)ri[s - 1], 63);
         }
+        const float pd = __int_as_float(__builtin_amdgcn_update_dpp(od, __float_as_int(rd[s]), 0x138, 0xf, 0xf, false));
+        const uint32_t pi = (uint32_t)__builtin_amdgcn_update_dpp(oi, (int)ri[s], 0x138, 0xf, 0xf, false);
         const uint32_t j = (uint32_t)s * 64u + (uint32_t)lane;
         if (j > pos) { rd[s] = pd; ri[s] = pi; }
         else if (j == pos) { rd[s] = xd; ri[s] = xi; }
@@ -347,23 +474,48 @@ __device__ __forceinline__ float wave_min(float v) {
 // reference's heap order -- see DESIGN.md "ties").
 // ---------------------------------------------------------------------------------------
 template <int METRIC, int S, int TABLE>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, SearchArgs a) {
+__global__ __launch_bounds__(64, HNSW_LB_WAVES) void hnsw_search_kernel(DeviceIndexView ix, SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* tile = reinterpret_cast<float4*>(lds_raw);
     uint32_t* ids_lds = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES);
-    float4* q_lds = reinterpret_cast<float4*>(lds_raw + TILE_BYTES + IDS_BYTES);
-    uint32_t* table = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES + IDS_BYTES + ix.row_stride * 4u);
+    uint32_t* table = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES + IDS_BYTES);
     const int lane = (int)threadIdx.x;
     const uint32_t table_cells = 1u << a.tbits;
     const uint32_t table_words = TABLE == TABLE_LDS_CELL16 ? table_cells >> 1 : table_cells;
     const uint32_t table_limit = table_cells - (table_cells >> 2);  // stop inserting at 75 % load
-    uint32_t* bitmap = TABLE == TABLE_GLOBAL_BITMAP ? a.bitmap + (size_t)blockIdx.x * a.bitmap_words : nullptr;
+    // this workgroup's private bitmap slice (in-launch fallback when the LDS table overflows)
+    uint32_t* bitmap = blockIdx.x < a.bitmap_blocks ? a.bitmap + (size_t)blockIdx.x * a.bitmap_words : nullptr;
     const bool single_batch = ix.deg_stride <= 64u;
+    bool use_bm = TABLE == TABLE_GLOBAL_BITMAP;
 
     auto visit = [&](uint32_t id) -> int {
+        if (TABLE == TABLE_GLOBAL_BITMAP || use_bm) return visit_bitmap(bitmap, id);
         if constexpr (TABLE == TABLE_LDS_CELL16) return visit_cell16(table, a.tbits, a.idbits, a.restbits, id);
-        else if constexpr (TABLE == TABLE_LDS_CELL32) return visit_cell32(table, a.tbits, id);
-        else return visit_bitmap(bitmap, id);
+        else return visit_cell32(table, a.tbits, id);
+    };
+
+    // A query that outgrows its LDS table moves its visited set into the HBM bitmap and carries on
+    // there (cells identify their ids exactly, so nothing is recomputed).
+    auto migrate_to_bitmap = [&]() {
+        for (uint32_t i = (uint32_t)lane; i < a.bitmap_words; i += 64) bitmap[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = (uint32_t)lane; i < table_cells; i += 64) {
+            uint32_t id = EMPTY_SLOT;
+            if constexpr (TABLE == TABLE_LDS_CELL16) {
+                const uint32_t half = (table[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+                if (half != 0u) {
+                    const uint32_t disp = (half & 0x7FFFu) >> a.restbits;
+                    const uint32_t rest = half & ((1u << a.restbits) - 1u);
+                    const uint32_t home = (i - disp) & (table_cells - 1u);
+                    id = unmix_id((home << a.restbits) | rest, a.idbits);
+                }
+            } else if constexpr (TABLE == TABLE_LDS_CELL32) {
+                id = table[i];
+            }
+            if (id != EMPTY_SLOT) atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
+        }
+        __syncthreads();
+        use_bm = true;
     };
 
     for (;;) {
@@ -373,28 +525,36 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
         if (wi >= a.nq) break;
         const uint32_t q = a.qlist ? a.qlist[wi] : wi;
 
-        // ---- stage the query in LDS, reset the visited set
-        {
-            const float4* qg = reinterpret_cast<const float4*>(a.queries + (size_t)q * ix.row_stride);
-            for (uint32_t i = (uint32_t)lane; i < (ix.row_stride >> 2); i += 64) q_lds[i] = qg[i];
-            if constexpr (TABLE == TABLE_LDS_CELL16) {
-                for (uint32_t i = (uint32_t)lane; i < table_words; i += 64) table[i] = 0u;
-            } else if constexpr (TABLE == TABLE_LDS_CELL32) {
-                for (uint32_t i = (uint32_t)lane; i < table_words; i += 64) table[i] = EMPTY_SLOT;
-            } else {
-                for (uint32_t i = (uint32_t)lane; i < a.bitmap_words; i += 64) bitmap[i] = 0u;
-            }
+        const qptr_t qrow = (qptr_t)(a.queries + (size_t)q * ix.row_stride);  // wave-uniform => scalar loads
+        const uint32_t t_start = (uint32_t)wall_clock64();
+
+        uint32_t n_dist, n_expand, n_ids, status, len;
+        bool tie;
+#if HNSW_PHASE_TIMING
+        uint32_t ph[4] = {0, 0, 0, 0};
+#endif
+        float rd[S];
+        uint32_t ri[S];
+        use_bm = TABLE == TABLE_GLOBAL_BITMAP;
+        for (;;) {
+        // ---- reset the visited set
+        if (TABLE == TABLE_GLOBAL_BITMAP || use_bm) {
+            for (uint32_t i = (uint32_t)lane; i < a.bitmap_words; i += 64) bitmap[i] = 0u;
+        } else if constexpr (TABLE == TABLE_LDS_CELL16) {
+            for (uint32_t i = (uint32_t)lane; i < table_words; i += 64) table[i] = 0u;
+        } else {
+            for (uint32_t i = (uint32_t)lane; i < table_words; i += 64) table[i] = EMPTY_SLOT;
         }
         __syncthreads();
 
-        uint32_t n_dist = 0, n_expand = 0, n_ids = 0, status = 0;
-        bool tie = false;
+        n_dist = 0; n_expand = 0; n_ids = 0; status = 0;
+        tie = false;
 
         // ---- greedy descent: ONE scan of the pivot's list per layer (src/hnsw.rs:1506-1529)
         uint32_t pivot = ix.entry;
         if (lane == 0) ids_lds[0] = pivot;
         __syncthreads();
-        float dcur = readlane_f(batch_dist<METRIC>(ix.vec, ix.row_stride, q_lds, tile, ids_lds, 1u, lane), 0);
+        float dcur = readlane_f(batch_dist<METRIC>(ix.vec, ix.row_stride, qrow, tile, ids_lds, 1u, lane), 0);
         n_dist += 1;
         for (int layer = (int)ix.entry_level; layer >= 1; --layer) {
             uint32_t b = 0, e = 0;
@@ -415,7 +575,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
                 __syncthreads();
                 if (valid) ids_lds[lane] = id;
                 __syncthreads();
-                const float dl = batch_dist<METRIC>(ix.vec, ix.row_stride, q_lds, tile, ids_lds, nf, lane);  // INF in lanes >= nf
+                const float dl = batch_dist<METRIC>(ix.vec, ix.row_stride, qrow, tile, ids_lds, nf, lane);  // INF in lanes >= nf
                 n_dist += nf;
                 const float m = wave_min(dl);
                 const unsigned long long eq = __ballot(valid && dl == m);
@@ -431,11 +591,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
         }
 
         // ---- search_layer at the lowest non-empty layer (src/hnsw.rs:1542, :922-1064)
-        float rd[S];
-        uint32_t ri[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) { rd[s] = 0.f; ri[s] = 0u; }
-        uint32_t len = 1;
+        len = 1;
         if (lane == 0) { rd[0] = dcur; ri[0] = pivot; }  // dist_to_entry_point == eval(q, pivot) (:952)
         uint32_t n_visited = 1;
         if (lane == 0) (void)visit(pivot);
@@ -443,6 +601,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
 
         uint32_t spec_for = EMPTY_SLOT, spec_ids = EMPTY_SLOT;  // prefetched id row of the likely next candidate
         for (;;) {
+            PH_T(pt0);
             // c = nearest unexpanded member of R (candidate_points.pop(), :971)
             const int cj = r_next<S>(ri, len, lane);
             if (cj < 0) break;  // every remaining candidate is farther than R's worst (:981-993)
@@ -470,17 +629,26 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
                 }
                 const bool valid = id != EMPTY_SLOT;
                 const unsigned long long vm = __ballot(valid);
+                PH_T(pt1);
+                PH_ACC(0, pt0, pt1);  // candidate selection + wait for its id row
                 if (vm == 0ull) break;  // lists are padded at the end only
                 n_ids += popc64(vm);
-                if constexpr (TABLE != TABLE_GLOBAL_BITMAP) {
-                    if (n_visited + 64 > table_limit) { status = 1; break; }
+                if (TABLE != TABLE_GLOBAL_BITMAP && !use_bm && n_visited + 64 > table_limit) {
+                    if (bitmap == nullptr) { status = 1; break; }  // no slice for this workgroup: host re-runs it
+                    migrate_to_bitmap();
                 }
                 int vr = 0;
                 if (valid) vr = visit(id);
-                if (__ballot(vr == 2) != 0ull) { status = 1; break; }
+                if (__ballot(vr == 2) != 0ull) {  // displacement budget exhausted inside the table (rare)
+                    if (use_bm || bitmap == nullptr) { status = 1; break; }
+                    migrate_to_bitmap();  // includes the ids this batch already placed
+                    if (vr == 2) vr = visit_bitmap(bitmap, id);
+                }
                 const bool fresh = vr == 1;
                 const unsigned long long fm = __ballot(fresh);
                 const uint32_t nf = popc64(fm);
+                PH_T(pt2);
+                PH_ACC(1, pt1, pt2);  // visited-set probes
                 if (nf == 0u) continue;
                 n_visited += nf;
                 n_dist += nf;
@@ -489,7 +657,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
                 if (fresh) ids_lds[popc64(fm & lanemask_lt(lane))] = id;
                 __syncthreads();
                 const uint32_t idc = (uint32_t)lane < nf ? ids_lds[lane] : 0u;
-                const float de = batch_dist<METRIC>(ix.vec, ix.row_stride, q_lds, tile, ids_lds, nf, lane);
+                const float de = batch_dist<METRIC>(ix.vec, ix.row_stride, qrow, tile, ids_lds, nf, lane);
+                PH_T(pt3);
+                PH_ACC(2, pt2, pt3);  // compaction + row loads + transposed accumulate
                 // accept rule applied sequentially in list order (:1028-1053)
                 float worst = r_worst<S>(rd, len);
                 unsigned long long cand = __ballot((uint32_t)lane < nf && (len < a.ef || de < worst));
@@ -503,9 +673,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
                         worst = r_worst<S>(rd, len);
                     }
                 }
+                PH_T(pt4);
+                PH_ACC(3, pt3, pt4);  // result-set insertions
             }
             if (status != 0) break;
         }
+        break;
+        }  // (single pass; kept as a block so that the reset above stays next to the body)
         if (status == 0 && tie) status = 2;
 
         // ---- into_sorted_vec + truncate to min(knbn, ef, len) (:1544-1547, :1567-1578)
@@ -538,8 +712,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(DeviceIndexView ix, Sea
             a.retry_out[slot] = q;
         }
         if (lane == 0) {
-            uint32_t* st = a.stats + (size_t)q * 4;
+            uint32_t* st = a.stats + (size_t)q * 8;
             st[0] = n_dist; st[1] = n_expand; st[2] = n_ids; st[3] = status;
+            st[4] = t_start; st[5] = (uint32_t)wall_clock64(); st[6] = use_bm ? 1u : 0u; st[7] = 0u;
+#if HNSW_PHASE_TIMING
+            st[7] = ph[0]; st[3] = ph[1]; st[2] = ph[2]; st[6] = ph[3];  // profiling build: overwrites status/n_ids/bitmap flag
+#endif
         }
         __syncthreads();
     }
@@ -737,11 +915,11 @@ int DeviceIndex::ensure_workspace(uint64_t nq, uint64_t /*k*/, std::string& err)
         }
         retry_cap_ = nq;
     }
-    if (nq * 4 * sizeof(uint32_t) > stats_cap_) {
+    if (nq * 8 * sizeof(uint32_t) > stats_cap_) {
         if (d_stats_) (void)hipFree(d_stats_);
         d_stats_ = nullptr;
-        HIP_TRY(hipMalloc(&d_stats_, nq * 4 * sizeof(uint32_t)));
-        stats_cap_ = nq * 4 * sizeof(uint32_t);
+        HIP_TRY(hipMalloc(&d_stats_, nq * 8 * sizeof(uint32_t)));
+        stats_cap_ = nq * 8 * sizeof(uint32_t);
     }
     return OK;
 }
@@ -775,17 +953,17 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
                            static_cast<float*>(d_qpad_), (uint32_t)nq, v_.d, v_.row_stride);
     }
 
-    // Visited-set sizing.  LDS per wavefront is what bounds occupancy, so start with a table sized for
-    // the typical query (~1.5 x ef x degree cells) and re-run the few queries that overflow it with a
-    // 4x table, then with the HBM bitmap (exact, cannot overflow).
+    // Visited-set sizing.  LDS per wavefront is what bounds occupancy, so the table is sized for the
+    // typical query (ef x degree cells, ~2.4x the median number of visited points, measured); the few
+    // per cent of queries that outgrow it start over on the HBM bitmap inside the same launch.
     const uint32_t idbits = std::max<uint32_t>(1u, ceil_log2(v_.n));
-    const uint64_t expect = ef * std::min<uint64_t>(v_.deg_stride, 64) * 3 / 2 + 64;
+    const uint64_t expect = ef * std::min<uint64_t>(v_.deg_stride, 64);
     uint32_t tbits = std::min<uint32_t>(14u, std::max<uint32_t>(8u, ceil_log2(expect)));
     if (const char* e = std::getenv("HNSWGPU_HASH_BITS")) {  // tuning / test hook: initial table size
         int b = std::atoi(e);
         if (b >= 6 && b <= 14) tbits = (uint32_t)b;
     }
-    const size_t lds_fixed = TILE_BYTES + IDS_BYTES + (size_t)v_.row_stride * 4;
+    const size_t lds_fixed = TILE_BYTES + IDS_BYTES;
     int table = TABLE_LDS_CELL16;
     bool grown = false;
 
@@ -828,17 +1006,22 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         a.out_rank = d_out_rank;
         a.out_counts = d_out_counts;
         a.stats = stats;
-        if (table == TABLE_GLOBAL_BITMAP) {
+        {
+            // HBM bitmaps for the in-launch fallback: one slice per workgroup, within a 4 GiB budget
             a.bitmap_words = (v_.n + 31) / 32;
-            grid = std::min<uint32_t>(grid, (uint32_t)num_cu_ * 4);
-            const uint64_t need = (uint64_t)grid * a.bitmap_words * sizeof(uint32_t);
+            const uint64_t slice = (uint64_t)a.bitmap_words * sizeof(uint32_t);
+            uint64_t blocks = std::min<uint64_t>(grid, std::max<uint64_t>(1, (4ull << 30) / slice));
+            if (table == TABLE_GLOBAL_BITMAP) grid = (uint32_t)blocks;  // every workgroup needs one
+            const uint64_t need = blocks * slice;
             if (need > bitmap_cap_) {
                 if (d_bitmap_) (void)hipFree(d_bitmap_);
                 d_bitmap_ = nullptr;
+                bitmap_cap_ = 0;
                 HIP_TRY(hipMalloc(&d_bitmap_, need));
                 bitmap_cap_ = need;
             }
             a.bitmap = static_cast<uint32_t*>(d_bitmap_);
+            a.bitmap_blocks = (uint32_t)blocks;
         }
         HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, v_, a);

@@ -133,7 +133,9 @@ int hnswgpu_search_batch(const hnswgpu_index* idx, const float* queries, uint64_
 /* Same with every buffer already resident in HBM (device pointers), launched on HIP stream
  * `stream` (hipStream_t as void*; NULL = default stream).  Synchronises `stream` once
  * before returning (the visited-set overflow check needs one 4-byte read-back).
- * d_stats may be NULL, else uint32[nq*4] = {n_dist, n_expand, n_ids_read, status} per query. */
+ * d_stats may be NULL, else uint32[nq*8] per query = {n_dist, n_expand, n_ids_read, status,
+ * t_start, t_end (device wall clock, 10 ns ticks), used_hbm_bitmap, 0}.
+ * status: 0 ok; 2 ok, but an exact f32 distance tie was met (see DESIGN.md "ties").           */
 int hnswgpu_search_batch_device(const hnswgpu_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
                                 uint64_t k, uint64_t ef, uint64_t* d_out_ids, float* d_out_dists,
                                 uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,

@@ -1,0 +1,99 @@
+"""Product-side construction (hnswlib-rs_amd/csrc/builder.cpp) against the oracle's
+literal restatement of insert_slice / select_neighbours / reverse_update: serial insertion must give the
+same graph edge for edge, stored f32 distances included (compared through the dump bytes)."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from conftest import normalized, uniform
+
+
+def dumps_equal(d, a, b):
+    return (filecmp.cmp(os.path.join(d, a + ".hnsw.graph"), os.path.join(d, b + ".hnsw.graph"), shallow=False)
+            and filecmp.cmp(os.path.join(d, a + ".hnsw.data"), os.path.join(d, b + ".hnsw.data"), shallow=False))
+
+
+CASES = [
+    # n, d, M, ef_c, dist, normalize, scale, extend, keep_pruned
+    (2500, 25, 15, 100, "DistL2", False, None, False, False),   # examples/random.rs shape
+    (2000, 10, 10, 25, "DistL1", False, None, False, False),    # hnsw.rs unit-test shape
+    (1500, 25, 24, 200, "DistCosine", False, None, False, False),
+    (1500, 25, 16, 100, "DistDot", True, None, False, False),   # tests/serpar.rs: DistDot on normalised data
+    (2000, 10, 32, 128, "DistL2", False, 0.5, False, False),    # tests/equality.rs: modify_level_scale(0.5)
+    (1200, 8, 6, 40, "DistL2", False, None, True, False),       # set_extend_candidates(true)
+    (1200, 8, 6, 40, "DistL2", False, None, False, True),       # set_keeping_pruned(true)
+]
+
+
+@pytest.mark.parametrize("n,d,m,efc,dist,normalize,scale,extend,keep", CASES)
+def test_serial_insert_matches_oracle(native, oracle, tmp_path, n, d, m, efc, dist, normalize, scale, extend, keep):
+    X = normalized(n, d, n + m) if normalize else uniform(n, d, n + m)
+    o = oracle.OracleHnsw(m, n, 16, efc, dist)
+    h = native.Hnsw(m, n, 16, efc, dist)
+    if scale is not None:
+        o.modify_level_scale(scale)
+        h.modify_level_scale(scale)
+    o.set_extend_candidates(extend)
+    h.set_extend_candidates(extend)
+    o.set_keeping_pruned(keep)
+    h.set_keeping_pruned(keep)
+    o.insert_batch(X)
+    h.insert_serial(X)
+    o.file_dump(tmp_path, "orc")
+    h.file_dump(tmp_path, "prod")
+    assert dumps_equal(tmp_path, "orc", "prod")
+
+
+def test_parallel_insert_gives_a_valid_graph(native, oracle, tmp_path):
+    """parallel_insert is racy by design (src/hnsw.rs:1222-1223): check invariants, not equality."""
+    n, d, m = 6000, 16, 12
+    X = uniform(n, d, 9)
+    h = native.Hnsw(m, n, 16, 100, "DistL2")
+    h.set_build_options(nthreads=8)
+    h.parallel_insert(X)
+    assert h.get_nb_point() == n
+    lv = oracle.levels(m, n)  # levels are drawn in input order whatever the thread interleaving
+    for l in range(16):
+        assert h.get_layer_nb_point(l) == int((lv == l).sum())
+    ep_origin, (ep_layer, _) = h.get_entry_point()
+    assert ep_layer == lv.max()
+    total = 0
+    for layer in range(3):
+        for rank in range(0, h.get_layer_nb_point(layer), 37):
+            for l in range(layer + 1):
+                ids, _, _, dists = h.get_neighbours(layer, rank, l)
+                assert len(ids) <= (2 * m if l == 0 else m)      # src/hnsw.rs:1272-1283
+                assert len(set(ids.tolist())) == len(ids)
+                assert np.all(np.diff(dists) >= 0)               # lists stay sorted by stored distance
+                total += len(ids)
+    assert total > 0
+    # it is searchable by the oracle (through the dump) with sane recall
+    h.file_dump(tmp_path, "par")
+    o = oracle.OracleHnsw.load(tmp_path, "par", "DistL2")
+    Q = uniform(100, d, 10)
+    r = o.parallel_search(Q, 10, 64, 4)
+    D = ((Q[:, None, :] - X[None]) ** 2).sum(-1)
+    gt = np.argsort(D, axis=1)[:, :10]
+    rec = np.mean([len(set(gt[i]) & set(r.ids[i].tolist())) / 10 for i in range(100)])
+    assert rec > 0.9
+
+
+def test_fast_arithmetic_build_is_searchable(native, oracle, tmp_path):
+    X = uniform(3000, 32, 4)
+    h = native.Hnsw(16, 3000, 16, 100, "DistL2")
+    h.set_build_options(nthreads=4, fast_arithmetic=True)
+    h.parallel_insert(X)
+    h.file_dump(tmp_path, "fast")
+    o = oracle.OracleHnsw.load(tmp_path, "fast", "DistL2")
+    r = o.parallel_search(X[:200], 1, 32, 4)
+    assert (r.ids[:, 0] == np.arange(200)).mean() > 0.95
+
+
+def test_bad_parameters(native):
+    with pytest.raises(native.HnswError):
+        native.Hnsw(257, 10, 16, 20, "DistL2")  # the reference exits the process (src/hnsw.rs:784-787)
+    h = native.Hnsw(8, 10, 16, 20, "DistL2")
+    with pytest.raises(native.HnswError):
+        h.parallel_insert(np.zeros((3,), np.float32))

@@ -128,8 +128,9 @@ def test_sqrt_correctly_rounded(native):
 
 @pytest.mark.parametrize("bits", [6, 8, 10])
 def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, monkeypatch):
-    """A visited table far too small for the query must not change results: overflowing queries are
-    re-run with a 4x table and finally with the HBM bitmap (HNSWGPU_HASH_BITS is a test/tuning hook)."""
+    """A visited table far too small for the query must not change results: a query that outgrows its
+    LDS table starts over, inside the same launch, on the exact HBM bitmap (HNSWGPU_HASH_BITS is a
+    test/tuning hook that forces a tiny table)."""
     X, o, h = build_pair(native, oracle, tmp_path, 4000, 32, 16, 100, "DistL2", seed=21)
     Q = uniform(300, 32, 22)
     ref = o.parallel_search(Q, 10, 100)
@@ -137,5 +138,4 @@ def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, monkeyp
     res = h.parallel_search_flat(Q, 10, 100)
     assert_same(res, ref)
     ms, launches = h.last_kernel_ms()
-    if bits <= 8:
-        assert launches >= 2
+    assert launches >= 1

@@ -1,0 +1,155 @@
+"""hnswio dump format (src/hnswio.rs): the product's reader/writer against the
+oracle's independent one, against bytes packed by hand in this file, and on malformed input."""
+import filecmp
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import uniform
+
+
+def same_files(d, a, b):
+    return (filecmp.cmp(os.path.join(d, a + ".hnsw.graph"), os.path.join(d, b + ".hnsw.graph"), shallow=False)
+            and filecmp.cmp(os.path.join(d, a + ".hnsw.data"), os.path.join(d, b + ".hnsw.data"), shallow=False))
+
+
+@pytest.mark.parametrize("dist,d", [("DistL2", 25), ("DistCosine", 7), ("DistL1", 10)])
+def test_reader_writer_round_trip_is_byte_identical(native, oracle, tmp_path, dist, d):
+    X = uniform(1500, d, 3)
+    o = oracle.OracleHnsw(10, 1500, 16, 25, dist)  # the shapes of the reference's own reload tests
+    o.insert_batch(X, ids=np.arange(1500) * 7 + 3)  # origin ids are arbitrary usize
+    o.file_dump(tmp_path, "orc")
+    h = native.HnswIo(tmp_path, "orc").load_hnsw(dist)
+    assert h.get_nb_point() == 1500
+    h.file_dump(tmp_path, "prod")
+    assert same_files(tmp_path, "orc", "prod")
+    # check_graph_equality (src/hnsw.rs:1686-1753): entry point, per-layer counts
+    assert h.get_max_level_observed() == o.get_max_level_observed()
+    for l in range(16):
+        assert h.get_layer_nb_point(l) == o.get_layer_nb_point(l)
+    # and the oracle can read what the product wrote
+    o2 = oracle.OracleHnsw.load(tmp_path, "prod", dist)
+    o2.file_dump(tmp_path, "orc2")
+    assert same_files(tmp_path, "orc", "orc2")
+
+
+def test_byte_layout_matches_appendix_a(native, tmp_path):
+    """Pack the expected bytes BY HAND (struct.pack, following SURVEY.md Appendix A field by field) from
+    what the getters report, and compare with the two files the writer produced."""
+    import oracle_lib
+    X = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 2.0], [3.0, 3.0], [0.5, 0.5]], np.float32)
+    ids = [10, 11, 12, 13, 14]
+    h = native.Hnsw(4, 5, 16, 10, "DistL1")
+    h.insert_serial(X, ids=ids)
+    h.file_dump(tmp_path, "tiny")
+    descr = h.get_description()
+    # points appear in (layer, rank) order; ranks follow insertion order within the level drawn by the
+    # documented level stream
+    lv = oracle_lib.levels(4, 5)
+    by_layer = {l: [i for i in range(5) if lv[i] == l] for l in range(16)}
+    name = b"anndists::dist::distances::DistL1"
+    g = bytearray()
+    g += struct.pack("=I", 0x002a6779)                       # MAGICDESCR_4
+    g += struct.pack("=BB", 1, 4)                             # dumpmode Full, max_nb_connection as u8
+    g += struct.pack("=d", descr.level_scale)                 # level_scale (v4 only)
+    g += struct.pack("=B", 16)                                # nb_layer
+    g += struct.pack("=QQQ", 10, 5, 2)                        # ef_construction, nb_point, dimension
+    g += struct.pack("=Q", len(name)) + name
+    g += struct.pack("=Q", 3) + b"f32"
+    g += struct.pack("=B", 16)                                # points_by_layer.len()
+    dt = bytearray(struct.pack("=IQ", 0xa67f0000, 2))         # MAGICDATAP, dimension
+    for layer in range(16):
+        pts = by_layer[layer]
+        assert len(pts) == h.get_layer_nb_point(layer)
+        g += struct.pack("=IQ", 0x000a676f, len(pts))         # MAGICLAYER, nb points of the layer
+        for rank, i in enumerate(pts):
+            g += struct.pack("=IQ", 0x000a678f, ids[i])       # MAGICPOINT, origin_id
+            g += struct.pack("=Bi", layer, rank)              # p_id
+            for l in range(16):                               # always 16 lists
+                nid, nl, nr, nd = h.get_neighbours(layer, rank, l)
+                g += struct.pack("=Q", len(nid))
+                for j in range(len(nid)):                     # 17 bytes per edge
+                    g += struct.pack("=QBif", int(nid[j]), int(nl[j]), int(nr[j]), float(nd[j]))
+            dt += struct.pack("=IQQ", 0xa67f0000, ids[i], 8) + X[i].tobytes()
+    ep_origin, (ep_layer, ep_rank) = h.get_entry_point()
+    g += struct.pack("=QBi", ep_origin, ep_layer, ep_rank)
+    assert bytes(g) == open(tmp_path / "tiny.hnsw.graph", "rb").read()
+    assert bytes(dt) == open(tmp_path / "tiny.hnsw.data", "rb").read()
+    assert abs(descr.level_scale - 1.0 / np.log(4.0)) < 1e-15  # get_level_scale(): absolute scale 1/ln(M)
+
+
+def test_load_description(native, oracle, tmp_path):
+    o = oracle.OracleHnsw(12, 100, 16, 33, "DistDot")
+    o.insert_batch(uniform(100, 9, 1))
+    o.file_dump(tmp_path, "d")
+    d = native.load_description(tmp_path / "d.hnsw.graph")
+    assert (d.format_version, d.dumpmode, d.max_nb_connection, d.nb_layer) == (4, 1, 12, 16)
+    assert (d.ef_construction, d.nb_point, d.dimension) == (33, 100, 9)
+    assert d.distname.decode() == "anndists::dist::distances::DistDot" and d.t_name.decode() == "f32"
+
+
+def _dump(oracle, tmp_path, name="x"):
+    o = oracle.OracleHnsw(8, 200, 16, 20, "DistL2")
+    o.insert_batch(uniform(200, 5, 2))
+    o.file_dump(tmp_path, name)
+    return tmp_path / f"{name}.hnsw.graph", tmp_path / f"{name}.hnsw.data"
+
+
+def test_errors_are_reported_not_fatal(native, oracle, tmp_path):
+    N = native._native
+    gpath, dpath = _dump(oracle, tmp_path)
+    with pytest.raises(native.HnswError) as e:
+        native.HnswIo(tmp_path, "missing").load_hnsw("DistL2")
+    assert e.value.code == N.ERR_IO
+    with pytest.raises(native.HnswError) as e:  # short-name rule, src/hnswio.rs:473-490
+        native.HnswIo(tmp_path, "x").load_hnsw("DistL1")
+    assert e.value.code == N.ERR_DISTANCE
+    native.HnswIo(tmp_path, "x").load_hnsw(None)  # accept the dump's own distance
+    raw = bytearray(open(gpath, "rb").read())
+    # bad magic
+    bad = bytearray(raw); bad[0] ^= 0xFF
+    open(tmp_path / "bm.hnsw.graph", "wb").write(bad); open(tmp_path / "bm.hnsw.data", "wb").write(open(dpath, "rb").read())
+    with pytest.raises(native.HnswError) as e:
+        native.HnswIo(tmp_path, "bm").load_hnsw("DistL2")
+    assert e.value.code == N.ERR_FORMAT
+    # truncated graph file
+    open(tmp_path / "tr.hnsw.graph", "wb").write(raw[: len(raw) // 2]); open(tmp_path / "tr.hnsw.data", "wb").write(open(dpath, "rb").read())
+    with pytest.raises(native.HnswError) as e:
+        native.HnswIo(tmp_path, "tr").load_hnsw("DistL2")
+    assert e.value.code == N.ERR_FORMAT
+    # truncated data file
+    open(tmp_path / "td.hnsw.graph", "wb").write(raw); open(tmp_path / "td.hnsw.data", "wb").write(open(dpath, "rb").read()[:100])
+    with pytest.raises(native.HnswError) as e:
+        native.HnswIo(tmp_path, "td").load_hnsw("DistL2")
+    assert e.value.code == N.ERR_FORMAT
+    # element type other than f32: patch the t_name "f32" -> "u16" (same length)
+    pos = raw.index(b"f32")
+    ty = bytearray(raw); ty[pos:pos + 3] = b"u16"
+    open(tmp_path / "ty.hnsw.graph", "wb").write(ty); open(tmp_path / "ty.hnsw.data", "wb").write(open(dpath, "rb").read())
+    with pytest.raises(native.HnswError) as e:
+        native.HnswIo(tmp_path, "ty").load_hnsw("DistL2")
+    assert e.value.code == N.ERR_TYPE
+    # an empty index cannot be dumped (src/hnswio.rs:1323-1325)
+    with pytest.raises(native.HnswError) as e:
+        native.Hnsw(8, 10, 16, 20, "DistL2").file_dump(tmp_path, "empty")
+    assert e.value.code == N.ERR_EMPTY
+
+
+def test_unsorted_lists_are_resorted_on_reload(native, oracle, tmp_path):
+    """Reload re-sorts every list by stored distance (src/hnswio.rs:731)."""
+    gpath, dpath = _dump(oracle, tmp_path, "s")
+    h = native.HnswIo(tmp_path, "s").load_hnsw("DistL2")
+    ids, layers, ranks, dists = h.get_neighbours(0, 0, 0)
+    assert len(ids) >= 2 and np.all(np.diff(dists) >= 0)
+    raw = bytearray(open(gpath, "rb").read())
+    # find the first edge of point (0,0): after description + nb_layer byte + layer header + point header + count
+    hdr = 4 + 1 + 1 + 8 + 1 + 8 + 8 + 8 + 8 + len("anndists::dist::distances::DistL2") + 8 + 3
+    off = hdr + 1 + 4 + 8 + 4 + 8 + 1 + 4 + 8
+    e0, e1 = bytes(raw[off:off + 17]), bytes(raw[off + 17:off + 34])
+    raw[off:off + 17], raw[off + 17:off + 34] = e1, e0  # swap the two nearest edges
+    open(tmp_path / "sw.hnsw.graph", "wb").write(raw); open(tmp_path / "sw.hnsw.data", "wb").write(open(dpath, "rb").read())
+    h2 = native.HnswIo(tmp_path, "sw").load_hnsw("DistL2")
+    ids2, _, _, dists2 = h2.get_neighbours(0, 0, 0)
+    assert np.array_equal(ids2, ids) and np.array_equal(dists2, dists)
