@@ -293,9 +293,21 @@ def main():
         sample = int(min(nq_local, max(probe, rate * args.cpu_seconds)))
         r = orc.parallel_search(Q[:sample], k, ef, cores)
         cpu_qps = sample / r.elapsed_s
-        same_ids = bool(np.array_equal(r.ids, res_ids[:sample].astype(np.uint64)) and np.array_equal(r.counts, cnt[:sample].astype(np.uint32)))
-        same_bits = bool(np.array_equal(r.dists.view(np.uint32), out_dists.cpu().numpy()[:sample].view(np.uint32)))
-        parity = {"queries_checked": sample, "ids_identical": same_ids, "f32_distance_bits_identical": same_bits}
+        # Parity at full size.  status 2 = the kernel met an exact f32 distance tie while inserting: the
+        # reference's answer then depends on its binary heaps' internal order (DESIGN.md "ties"), so those
+        # queries are reported separately.
+        gpu_ids = res_ids[:sample].astype(np.uint64)
+        gpu_bits = out_dists.cpu().numpy()[:sample].view(np.uint32)
+        tie_flag = st[:sample, 3] == 2
+        row_ids_ok = np.all(r.ids == gpu_ids, axis=1) & (r.counts == cnt[:sample].astype(np.uint32))
+        row_bits_ok = np.all(r.dists.view(np.uint32) == gpu_bits, axis=1)
+        parity = {"queries_checked": int(sample),
+                  "tie_free_queries": int((~tie_flag).sum()),
+                  "tie_free_ids_identical": bool(row_ids_ok[~tie_flag].all()),
+                  "tie_free_f32_distance_bits_identical": bool(row_bits_ok[~tie_flag].all()),
+                  "queries_with_exact_distance_tie": int(tie_flag.sum()),
+                  "tied_queries_ids_identical": int(row_ids_ok[tie_flag].sum()),
+                  "tied_queries_distance_bits_identical": int(row_bits_ok[tie_flag].sum())}
         cpu_baseline = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                         "sample": f"first {sample} of the same {nq_local} queries, same graph (reloaded from the same hnswio dump), "
                                   f"oracle parallel_search with one thread per logical core, {r.elapsed_s:.1f} s"}
