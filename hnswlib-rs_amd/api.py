@@ -203,6 +203,15 @@ class Hnsw:
         _check(self._lib.hnswgpu_file_dump(self._h, str(path).encode(), file_basename.encode()))
         return file_basename
 
+    def set_strict_ties(self, on=True):
+        """Extension: replay tie-affected queries with a literal emulation of the reference's heaps."""
+        _check(self._lib.hnswgpu_set_strict_ties(self._h, int(bool(on))))
+
+    def last_tie_count(self):
+        n = C.c_uint32()
+        _check(self._lib.hnswgpu_last_tie_count(self._h, C.byref(n)))
+        return n.value
+
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_uint32()
         _check(self._lib.hnswgpu_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))

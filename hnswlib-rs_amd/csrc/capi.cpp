@@ -28,6 +28,7 @@ struct hnswgpu_index {
     bool flat_stale = false;
     std::unique_ptr<DeviceIndex> dev;
     bool dev_stale = true;
+    int strict_ties = -1;  // -1: library default (env HNSWGPU_STRICT_TIES, else on)
     BuildParams params;
 
     const FlatIndex* get_flat() {
@@ -60,6 +61,7 @@ static int ensure_device(hnswgpu_index* idx, int device) {
         return fail(rc, err);
     }
     idx->dev_stale = false;
+    if (idx->strict_ties >= 0) idx->dev->set_strict_ties(idx->strict_ties != 0);
     return HNSWGPU_OK;
 }
 
@@ -273,6 +275,20 @@ int hnswgpu_last_kernel_ms(const hnswgpu_index* cidx, double* ms, uint32_t* laun
     if (!idx || !idx->dev) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
     if (ms) *ms = idx->dev->last_kernel_ms();
     if (launches) *launches = idx->dev->last_launches();
+    return HNSWGPU_OK;
+}
+
+int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on) {
+    if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->strict_ties = on != 0;
+    if (idx->dev) idx->dev->set_strict_ties(idx->strict_ties);
+    return HNSWGPU_OK;
+}
+int hnswgpu_last_tie_count(const hnswgpu_index* cidx, uint32_t* ties) {
+    hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
+    if (!idx || !idx->dev || !ties) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
+    *ties = idx->dev->last_ties();
     return HNSWGPU_OK;
 }
 

@@ -77,6 +77,7 @@ struct SearchArgs {
     uint32_t* bitmap;       // [bitmap_blocks][bitmap_words]: per-workgroup visited bitmaps in HBM
     uint32_t bitmap_words;
     uint32_t bitmap_blocks; // workgroups with blockIdx.x < bitmap_blocks own a slice
+    uint32_t* tie_list;     // strict ties: queries that met an exact distance tie (count at overflow_count + 3)
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(64, HNSW_LB_WAVES) void hnsw_search_kernel(DeviceIn
         const qptr_t qrow = (qptr_t)(a.queries + (size_t)q * ix.row_stride);  // wave-uniform => scalar loads
         const uint32_t t_start = (uint32_t)wall_clock64();
 
-        uint32_t n_dist, n_expand, n_ids, status, len;
+        uint32_t n_dist, n_expand, n_ids, status, len, n_visited_final = 0;
         bool tie;
 #if HNSW_PHASE_TIMING
         uint32_t ph[4] = {0, 0, 0, 0};
@@ -678,9 +679,13 @@ __global__ __launch_bounds__(64, HNSW_LB_WAVES) void hnsw_search_kernel(DeviceIn
             }
             if (status != 0) break;
         }
+        n_visited_final = n_visited;
         break;
         }  // (single pass; kept as a block so that the reset above stays next to the body)
-        if (status == 0 && tie) status = 2;
+        if (status == 0 && tie) {
+            status = 2;
+            if (a.tie_list != nullptr && lane == 0) a.tie_list[atomicAdd(a.overflow_count + 3, 1u)] = q;
+        }
 
         // ---- into_sorted_vec + truncate to min(knbn, ef, len) (:1544-1547, :1567-1578)
         if (status != 1) {
@@ -711,6 +716,11 @@ __global__ __launch_bounds__(64, HNSW_LB_WAVES) void hnsw_search_kernel(DeviceIn
             const uint32_t slot = atomicAdd(a.overflow_count, 1u);
             a.retry_out[slot] = q;
         }
+        if (lane == 0 && TABLE != TABLE_GLOBAL_BITMAP) {
+            // feedback for the host's table sizing (ctrl[2], ctrl[3])
+            if (use_bm) atomicAdd(a.overflow_count + 1, 1u);
+            if (n_visited_final > (table_limit >> 1)) atomicAdd(a.overflow_count + 2, 1u);
+        }
         if (lane == 0) {
             uint32_t* st = a.stats + (size_t)q * 8;
             st[0] = n_dist; st[1] = n_expand; st[2] = n_ids; st[3] = status;
@@ -718,6 +728,276 @@ __global__ __launch_bounds__(64, HNSW_LB_WAVES) void hnsw_search_kernel(DeviceIn
 #if HNSW_PHASE_TIMING
             st[7] = ph[0]; st[3] = ph[1]; st[2] = ph[2]; st[6] = ph[3];  // profiling build: overwrites status/n_ids/bitmap flag
 #endif
+        }
+        __syncthreads();
+    }
+}
+
+
+// =======================================================================================
+// Exact replay of tie-affected queries ("strict ties").
+//
+// With two EQUAL f32 distances the reference's choice depends on the sift history of Rust's
+// std::collections::BinaryHeap.  Queries flagged status 2 by the main kernel are
+// re-run here with both heaps (candidate_points on -dist, return_points on +dist) emulated literally:
+// push = append + sift_up, pop = swap-remove + sift_down_to_bottom + sift_up, into_sorted_vec = repeated
+// swap + sift_down_range.  A sift only ever touches one root-to-leaf path, so the wave performs each heap
+// operation cooperatively: lanes load the ancestors (push) or the 62 descendants of the current node
+// within 5 levels (pop), the path is chased with readlane, and the shifted entries are stored in
+// parallel.  Heaps live in an L2-resident scratch slice of the workgroup (entries = {key f32, id u32}),
+// accessed with L1-bypassing relaxed agent-scope atomics.
+// =======================================================================================
+typedef unsigned long long hent_t;
+__device__ __forceinline__ hent_t hmake(float key, uint32_t id) { return ((hent_t)__float_as_uint(key) << 32) | id; }
+__device__ __forceinline__ float hkey(hent_t e) { return __uint_as_float((uint32_t)(e >> 32)); }
+__device__ __forceinline__ uint32_t hid(hent_t e) { return (uint32_t)e; }
+__device__ __forceinline__ hent_t hload(const hent_t* H, uint32_t i) {
+    return __hip_atomic_load(H + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hstore(hent_t* H, uint32_t i, hent_t v) {
+    __hip_atomic_store(H + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hfence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ hent_t readlane_h(hent_t v, int lane) {
+    const uint32_t lo = readlane_u((uint32_t)v, lane), hi = readlane_u((uint32_t)(v >> 32), lane);
+    return ((hent_t)hi << 32) | lo;
+}
+
+// BinaryHeap::push: data.push(item); sift_up(0, old_len): while pos > 0 { if elt <= data[parent] break; move parent down }
+__device__ __forceinline__ void heap_push(hent_t* H, uint32_t& len, hent_t item, int lane) {
+    const uint32_t pos = len;
+    len += 1;
+    // ancestor j of pos is ((pos+1) >> j) - 1
+    const uint32_t p1 = lane < 32 ? (pos + 1u) >> lane : 0u;
+    const bool anc = lane >= 1 && p1 >= 1u;
+    const hent_t e = anc ? hload(H, p1 - 1u) : 0ull;
+    const unsigned long long am = __ballot(anc);
+    const unsigned long long stop = __ballot(anc && hkey(item) <= hkey(e));
+    const int depth = (int)popc64(am);                       // ancestors are lanes 1..depth
+    const int moved = stop != 0ull ? ctz64(stop) - 1 : depth;  // how many ancestors move down one step
+    if (lane >= 1 && lane <= moved) hstore(H, ((pos + 1u) >> (lane - 1)) - 1u, e);
+    if (lane == 0) hstore(H, ((pos + 1u) >> moved) - 1u, item);
+    hfence();
+}
+
+// Greater-child path from the root of H[0..end): at a node with two children take the right one when
+// data[left] <= data[right], with only a left child take it.  Returns the number m of path nodes below the
+// root; lane j (1..m) receives the j-th node's index and entry, lane 0 index 0.
+__device__ __forceinline__ int heap_chase(const hent_t* H, uint32_t end, int lane, uint32_t& my_pos, hent_t& my_ent) {
+    int m = 0;
+    uint32_t p = 0;
+    my_pos = 0;
+    my_ent = 0ull;
+    for (;;) {
+        // lane L <= 62 holds the descendant of p at relative depth t = floor(log2(L+1)), offset L+1-2^t
+        const uint32_t L1 = (uint32_t)lane + 1u;
+        const uint32_t t = 31u - (uint32_t)__clz((int)L1);
+        const unsigned long long idx64 = (((unsigned long long)p + 1ull) << t) - 1ull + (unsigned long long)(L1 - (1u << t));
+        const bool valid = lane < 63 && idx64 < (unsigned long long)end;
+        const uint32_t idx = (uint32_t)idx64;
+        const hent_t e = valid ? hload(H, idx) : 0ull;
+        const unsigned long long vm = __ballot(valid);
+        int cur = 0;
+        bool bottom = false;
+        for (int step = 0; step < 5; ++step) {
+            const int l = 2 * cur + 1, r = l + 1;
+            if (((vm >> l) & 1ull) == 0ull) { bottom = true; break; }
+            int nxt = l;
+            if ((vm >> r) & 1ull) {
+                const float kl = hkey(readlane_h(e, l)), kr = hkey(readlane_h(e, r));
+                nxt = (kl <= kr) ? r : l;
+            }
+            m += 1;
+            const hent_t en = readlane_h(e, nxt);
+            const uint32_t ip = readlane_u(idx, nxt);
+            if (lane == m) { my_pos = ip; my_ent = en; }
+            cur = nxt;
+        }
+        if (bottom) break;
+        p = readlane_u(idx, cur);
+    }
+    return m;
+}
+
+// BinaryHeap::pop: swap-remove the root with the last element, sift_down_to_bottom(0), then sift_up.
+__device__ __forceinline__ hent_t heap_pop(hent_t* H, uint32_t& len, int lane) {
+    const hent_t last = hload(H, len - 1u);
+    len -= 1;
+    if (len == 0u) return last;
+    const hent_t root = hload(H, 0u);
+    uint32_t my_pos;
+    hent_t my_ent;
+    const int m = heap_chase(H, len, lane, my_pos, my_ent);
+    // the element re-inserted at the bottom climbs back while it is > the entry above it
+    const unsigned long long le = __ballot(lane >= 1 && lane <= m && hkey(last) <= hkey(my_ent));
+    const int jstar = le != 0ull ? 63 - __clzll((long long)le) : 0;
+    const uint32_t prev_pos = (uint32_t)__shfl_up((int)my_pos, 1);
+    if (lane >= 1 && lane <= jstar) hstore(H, prev_pos, my_ent);
+    if (lane == jstar) hstore(H, my_pos, last);
+    hfence();
+    return root;
+}
+
+// sift_down_range(0, end) of into_sorted_vec: descend along the greater child, stop as soon as elt >= child
+__device__ __forceinline__ void heap_sift_down_range(hent_t* H, uint32_t end, int lane) {
+    const hent_t elt = hload(H, 0u);
+    uint32_t my_pos;
+    hent_t my_ent;
+    const int m = heap_chase(H, end, lane, my_pos, my_ent);
+    const unsigned long long ge = __ballot(lane >= 1 && lane <= m && hkey(elt) >= hkey(my_ent));
+    const int nshift = ge != 0ull ? ctz64(ge) - 1 : m;
+    const uint32_t prev_pos = (uint32_t)__shfl_up((int)my_pos, 1);
+    if (lane >= 1 && lane <= nshift) hstore(H, prev_pos, my_ent);
+    if (lane == nshift) hstore(H, my_pos, elt);
+    hfence();
+}
+
+struct ExactArgs {
+    hent_t* heaps;        // [gridDim.x][heap_stride]: return_points (ef + 2 entries) then candidate_points
+    uint64_t heap_stride; // entries per workgroup
+    uint32_t cand_cap;    // capacity of candidate_points
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void hnsw_search_exact_kernel(DeviceIndexView ix, SearchArgs a, ExactArgs x) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4* tile = reinterpret_cast<float4*>(lds_raw);
+    uint32_t* ids_lds = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES);
+    const int lane = (int)threadIdx.x;
+    uint32_t* bitmap = a.bitmap + (size_t)blockIdx.x * a.bitmap_words;
+    hent_t* R = x.heaps + (size_t)blockIdx.x * x.heap_stride;
+    hent_t* Cq = R + (a.ef + 2u);
+
+    for (;;) {
+        uint32_t wi = 0;
+        if (lane == 0) wi = atomicAdd(a.work_counter, 1u);
+        wi = readlane_u(wi, 0);
+        if (wi >= a.nq) break;
+        const uint32_t q = a.qlist[wi];
+        const qptr_t qrow = (qptr_t)(a.queries + (size_t)q * ix.row_stride);
+        for (uint32_t i = (uint32_t)lane; i < a.bitmap_words; i += 64) bitmap[i] = 0u;
+        __syncthreads();
+        uint32_t n_dist = 0, n_expand = 0, n_ids = 0, status = 0;
+
+        // ---- descent, identical to the main kernel (src/hnsw.rs:1506-1529)
+        uint32_t pivot = ix.entry;
+        if (lane == 0) ids_lds[0] = pivot;
+        __syncthreads();
+        float dcur = readlane_f(batch_dist<METRIC>(ix.vec, ix.row_stride, qrow, tile, ids_lds, 1u, lane), 0);
+        n_dist += 1;
+        for (int layer = (int)ix.entry_level; layer >= 1; --layer) {
+            uint32_t b = 0, e = 0;
+            if ((uint32_t)layer <= ix.n_up_layers) {
+                const uint32_t* ptr = ix.up_ptr + (size_t)(layer - 1) * ((size_t)ix.n + 1);
+                b = ptr[pivot];
+                e = ptr[pivot + 1];
+            }
+            n_expand += 1;
+            n_ids += e - b;
+            float best = INFINITY;
+            uint32_t best_id = pivot;
+            for (uint32_t base = b; base < e; base += 64) {
+                const uint32_t j = base + (uint32_t)lane;
+                const bool valid = j < e;
+                const uint32_t id = valid ? ix.up_ids[j] : 0u;
+                const uint32_t nf = e - base < 64u ? e - base : 64u;
+                __syncthreads();
+                if (valid) ids_lds[lane] = id;
+                __syncthreads();
+                const float dl = batch_dist<METRIC>(ix.vec, ix.row_stride, qrow, tile, ids_lds, nf, lane);
+                n_dist += nf;
+                const float m = wave_min(dl);
+                const unsigned long long eq = __ballot(valid && dl == m);
+                if (eq != 0ull && m < best) { best = m; best_id = readlane_u(id, ctz64(eq)); }
+            }
+            if (best < dcur) { dcur = best; pivot = best_id; }
+        }
+
+        // ---- search_layer with literal heaps (src/hnsw.rs:938-1063)
+        uint32_t lenR = 0, lenC = 0;
+        if (lane == 0) (void)visit_bitmap(bitmap, pivot);
+        __syncthreads();
+        heap_push(Cq, lenC, hmake(-dcur, pivot), lane);
+        heap_push(R, lenR, hmake(dcur, pivot), lane);
+        while (lenC > 0u) {
+            const hent_t c = heap_pop(Cq, lenC, lane);                      // :971
+            float worst = hkey(hload(R, 0u));                               // :973 peek
+            if (-hkey(c) > worst) break;                                    // :981-993
+            n_expand += 1;
+            const uint32_t* nrow = ix.nbr0 + (size_t)hid(c) * ix.deg_stride;
+            const uint32_t nbatch = (ix.deg_stride + 63u) >> 6;
+            for (uint32_t bi = 0; bi < nbatch; ++bi) {
+                const uint32_t j = bi * 64u + (uint32_t)lane;
+                const uint32_t id = j < ix.deg_stride ? nrow[j] : EMPTY_SLOT;
+                const bool valid = id != EMPTY_SLOT;
+                const unsigned long long vm = __ballot(valid);
+                if (vm == 0ull) break;
+                n_ids += popc64(vm);
+                const bool fresh = valid && visit_bitmap(bitmap, id) == 1;  // :1016-1017
+                const unsigned long long fm = __ballot(fresh);
+                const uint32_t nf = popc64(fm);
+                if (nf == 0u) continue;
+                n_dist += nf;
+                __syncthreads();
+                if (fresh) ids_lds[popc64(fm & lanemask_lt(lane))] = id;
+                __syncthreads();
+                const uint32_t idc = (uint32_t)lane < nf ? ids_lds[lane] : 0u;
+                const float de = batch_dist<METRIC>(ix.vec, ix.row_stride, qrow, tile, ids_lds, nf, lane);
+                for (uint32_t r = 0; r < nf; ++r) {                          // list order (:1013)
+                    const float xd = readlane_f(de, (int)r);
+                    if (xd < worst || lenR < a.ef) {                        // :1028
+                        const uint32_t xi = readlane_u(idc, (int)r);
+                        if (lenC >= x.cand_cap) { status = 1; break; }
+                        heap_push(Cq, lenC, hmake(-xd, xi), lane);          // :1035-1036
+                        heap_push(R, lenR, hmake(xd, xi), lane);            // :1038
+                        if (lenR > a.ef) (void)heap_pop(R, lenR, lane);     // :1051-1053
+                        worst = hkey(hload(R, 0u));
+                    }
+                }
+                if (status != 0) break;
+            }
+            if (status != 0) break;
+        }
+
+        // ---- into_sorted_vec (:1544) + truncate (:1547)
+        if (status == 0) {
+            uint32_t end = lenR;
+            while (end > 1u) {
+                end -= 1;
+                if (lane == 0) {
+                    const hent_t r0 = hload(R, 0u), re = hload(R, end);
+                    hstore(R, 0u, re);
+                    hstore(R, end, r0);
+                }
+                hfence();
+                heap_sift_down_range(R, end, lane);
+            }
+            const uint32_t cnt = lenR < a.k ? lenR : a.k;
+            for (uint32_t j = (uint32_t)lane; j < a.k; j += 64) {
+                const size_t o = (size_t)q * a.k + j;
+                if (j < cnt) {
+                    const hent_t e = hload(R, j);
+                    const uint32_t flat = hid(e);
+                    uint32_t l = 0;
+                    while (l + 1 < NB_LAYER_MAX && flat >= ix.layer_offset[l + 1]) ++l;
+                    a.out_ids[o] = ix.origin_id[flat];
+                    a.out_dists[o] = hkey(e);
+                    if (a.out_layer) a.out_layer[o] = (uint8_t)l;
+                    if (a.out_rank) a.out_rank[o] = (int32_t)(flat - ix.layer_offset[l]);
+                } else {
+                    a.out_ids[o] = 0ull;
+                    a.out_dists[o] = 0.f;
+                    if (a.out_layer) a.out_layer[o] = 0;
+                    if (a.out_rank) a.out_rank[o] = 0;
+                }
+            }
+            if (lane == 0) a.out_counts[q] = cnt;
+        } else if (lane == 0) {
+            atomicAdd(a.overflow_count, 1u);
+        }
+        if (lane == 0) {
+            uint32_t* st = a.stats + (size_t)q * 8;
+            st[0] = n_dist; st[1] = n_expand; st[2] = n_ids; st[3] = status == 0 ? 3u : 4u;  // 3 = exact replay done
         }
         __syncthreads();
     }
@@ -799,7 +1079,7 @@ DeviceIndex::~DeviceIndex() { release(); }
 void DeviceIndex::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
     void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_qpad_, &d_ctrl_, &d_retry_[0], &d_retry_[1],
-                     &d_stats_, &d_bitmap_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
+                     &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
     for (void** p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (ev_start_) { (void)hipEventDestroy((hipEvent_t)ev_start_); ev_start_ = nullptr; }
@@ -808,6 +1088,7 @@ void DeviceIndex::release() {
 }
 
 int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
+    if (const char* e = std::getenv("HNSWGPU_STRICT_TIES")) strict_ties_ = std::atoi(e) != 0;
     if (x.n == 0 || x.entry_flat == NO_POINT) { err = "cannot upload an empty index"; return ERR_EMPTY; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device visible (a gfx950 GPU is required; there is no CPU fallback)"; return ERR_DEVICE; }
@@ -907,6 +1188,12 @@ int DeviceIndex::ensure_workspace(uint64_t nq, uint64_t /*k*/, std::string& err)
         HIP_TRY(hipMalloc(&d_qpad_, qpad_need));
         qpad_cap_ = qpad_need;
     }
+    if (nq > tie_cap_) {
+        if (d_tie_) (void)hipFree(d_tie_);
+        d_tie_ = nullptr;
+        HIP_TRY(hipMalloc(&d_tie_, nq * sizeof(uint32_t)));
+        tie_cap_ = nq;
+    }
     if (nq > retry_cap_) {
         for (int i = 0; i < 2; ++i) {
             if (d_retry_[i]) (void)hipFree(d_retry_[i]);
@@ -959,18 +1246,24 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     const uint32_t idbits = std::max<uint32_t>(1u, ceil_log2(v_.n));
     const uint64_t expect = ef * std::min<uint64_t>(v_.deg_stride, 64);
     uint32_t tbits = std::min<uint32_t>(14u, std::max<uint32_t>(8u, ceil_log2(expect)));
+    // ... then follows what the previous batches with the same ef measured (adapt_* below)
+    if (adapt_ef_ == ef && adapt_tbits_ != 0) tbits = adapt_tbits_;
+    bool env_forced = false;
     if (const char* e = std::getenv("HNSWGPU_HASH_BITS")) {  // tuning / test hook: initial table size
         int b = std::atoi(e);
-        if (b >= 6 && b <= 14) tbits = (uint32_t)b;
+        if (b >= 6 && b <= 14) { tbits = (uint32_t)b; env_forced = true; }
     }
+    const uint32_t tbits_first = tbits;
     const size_t lds_fixed = TILE_BYTES + IDS_BYTES;
     int table = TABLE_LDS_CELL16;
     bool grown = false;
 
     uint32_t launches = 0;
     uint32_t work = (uint32_t)nq;
+    uint32_t n_ties = 0;
     const uint32_t* qlist = nullptr;
     int pingpong = 0;
+    SearchArgs last_args{};
     for (;;) {
         SearchArgs a{};
         size_t lds = lds_fixed;
@@ -1023,13 +1316,25 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             a.bitmap = static_cast<uint32_t*>(d_bitmap_);
             a.bitmap_blocks = (uint32_t)blocks;
         }
-        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
+        a.tie_list = strict_ties_ ? static_cast<uint32_t*>(d_tie_) : nullptr;
+        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, launches == 0 ? 32 : 16, stream));  // the tie list spans relaunches
         hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, v_, a);
         HIP_TRY(hipGetLastError());
+        last_args = a;
         ++launches;
-        uint32_t ctrl[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(ctrl, d_ctrl_, 8, hipMemcpyDeviceToHost, stream));
+        uint32_t ctrl[5] = {0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(ctrl, d_ctrl_, 20, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        n_ties = ctrl[4];
+        if (launches == 1 && table != TABLE_GLOBAL_BITMAP && !env_forced && nq >= 256) {
+            // Table sizing feedback for the next batch: grow when more than ~1 query in 8 had to move to the
+            // HBM bitmap, shrink when a half-size table would have overflowed for fewer than 1 in 32.
+            uint32_t next = tbits_first;
+            if ((uint64_t)ctrl[2] * 8 > nq && tbits_first < 14u) next = tbits_first + 1;
+            else if ((uint64_t)ctrl[3] * 32 < nq && tbits_first > 8u) next = tbits_first - 1;
+            adapt_ef_ = ef;
+            adapt_tbits_ = next;
+        }
         if (ctrl[1] == 0) break;
         // some queries visited more points than the table holds: rerun only those
         work = ctrl[1];
@@ -1042,6 +1347,53 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         } else {
             table = TABLE_GLOBAL_BITMAP;
         }
+    }
+    last_ties_ = n_ties;
+    if (strict_ties_ && n_ties > 0) {
+        // Exact replay of the tie-affected queries with literal binary heaps (hnsw_search_exact_kernel).
+        const uint64_t bm_slice = (uint64_t)last_args.bitmap_words * sizeof(uint32_t);
+        const uint64_t cand_cap = v_.n;                                   // every point is accepted at most once
+        const uint64_t heap_stride = ef + 2 + cand_cap;
+        const uint64_t per_block = bm_slice + heap_stride * sizeof(hent_t);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(n_ties, std::max<uint64_t>(1, (2ull << 30) / per_block));
+        grid = std::min<uint32_t>(grid, (uint32_t)num_cu_ * 4u);
+        if ((uint64_t)grid * bm_slice > bitmap_cap_) {
+            if (d_bitmap_) (void)hipFree(d_bitmap_);
+            d_bitmap_ = nullptr;
+            bitmap_cap_ = 0;
+            HIP_TRY(hipMalloc(&d_bitmap_, (uint64_t)grid * bm_slice));
+            bitmap_cap_ = (uint64_t)grid * bm_slice;
+        }
+        if ((uint64_t)grid * heap_stride * sizeof(hent_t) > heaps_cap_) {
+            if (d_heaps_) (void)hipFree(d_heaps_);
+            d_heaps_ = nullptr;
+            heaps_cap_ = 0;
+            HIP_TRY(hipMalloc(&d_heaps_, (uint64_t)grid * heap_stride * sizeof(hent_t)));
+            heaps_cap_ = (uint64_t)grid * heap_stride * sizeof(hent_t);
+        }
+        SearchArgs a = last_args;
+        a.qlist = static_cast<const uint32_t*>(d_tie_);
+        a.nq = n_ties;
+        a.bitmap = static_cast<uint32_t*>(d_bitmap_);
+        a.tie_list = nullptr;
+        ExactArgs x{};
+        x.heaps = static_cast<hent_t*>(d_heaps_);
+        x.heap_stride = heap_stride;
+        x.cand_cap = (uint32_t)cand_cap;
+        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
+        const size_t lds = TILE_BYTES + IDS_BYTES;
+        switch (dist_) {
+            case DIST_L2: hipLaunchKernelGGL(hnsw_search_exact_kernel<DIST_L2>, dim3(grid), dim3(64), lds, stream, v_, a, x); break;
+            case DIST_COSINE: hipLaunchKernelGGL(hnsw_search_exact_kernel<DIST_COSINE>, dim3(grid), dim3(64), lds, stream, v_, a, x); break;
+            case DIST_DOT: hipLaunchKernelGGL(hnsw_search_exact_kernel<DIST_DOT>, dim3(grid), dim3(64), lds, stream, v_, a, x); break;
+            default: hipLaunchKernelGGL(hnsw_search_exact_kernel<DIST_L1>, dim3(grid), dim3(64), lds, stream, v_, a, x); break;
+        }
+        HIP_TRY(hipGetLastError());
+        ++launches;
+        uint32_t ctrl2[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(ctrl2, d_ctrl_, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (ctrl2[1] != 0) { err = "internal error: candidate heap overflow in the exact replay"; return ERR_DEVICE; }
     }
     HIP_TRY(hipEventRecord((hipEvent_t)ev_stop_, stream));
     HIP_TRY(hipEventSynchronize((hipEvent_t)ev_stop_));

@@ -47,6 +47,10 @@ public:
     int search_host(const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids,
                     float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts, std::string& err);
 
+    // strict ties: re-run tie-affected queries with a literal emulation of the reference's binary heaps
+    void set_strict_ties(bool on) { strict_ties_ = on; }
+    bool strict_ties() const { return strict_ties_; }
+    uint32_t last_ties() const { return last_ties_; }
     double last_kernel_ms() const { return last_ms_; }
     uint32_t last_launches() const { return last_launches_; }
 
@@ -75,6 +79,12 @@ private:
     uint64_t hostio_cap_q_ = 0, hostio_cap_k_ = 0, hostio_cap_n_ = 0;
     void* ev_start_ = nullptr;
     void* ev_stop_ = nullptr;
+    void* d_tie_ = nullptr;       uint64_t tie_cap_ = 0;      // queries flagged with an exact distance tie
+    void* d_heaps_ = nullptr;     uint64_t heaps_cap_ = 0;    // scratch of the exact replay
+    bool strict_ties_ = true;
+    uint32_t last_ties_ = 0;
+    uint64_t adapt_ef_ = 0;       // visited-table sizing learned from previous batches with this ef
+    uint32_t adapt_tbits_ = 0;
     double last_ms_ = 0.0;
     uint32_t last_launches_ = 0;
 };

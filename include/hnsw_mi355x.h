@@ -141,6 +141,14 @@ int hnswgpu_search_batch_device(const hnswgpu_index* idx, const float* d_queries
                                 uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
                                 uint32_t* d_stats, void* stream);
 
+/* Ties.  Two EQUAL f32 distances make the reference's answer depend on the internal order of Rust's
+ * BinaryHeap.  The fast kernel orders equals by arrival and flags such queries (stats status 2);
+ * with strict ties ON (default; env HNSWGPU_STRICT_TIES=0 or this call turns it off) the flagged
+ * queries are re-run by a second kernel that emulates both heaps literally, so that ids match the
+ * reference bit for bit also under ties.  hnswgpu_last_tie_count: flagged queries of the last call. */
+int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on);
+int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
+
 /* Timing of the kernels of the last search call on this index, measured with HIP events on
  * the launch stream: total milliseconds and number of launches (retries included).        */
 int hnswgpu_last_kernel_ms(const hnswgpu_index* idx, double* ms, uint32_t* launches);

@@ -139,3 +139,39 @@ def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, monkeyp
     assert_same(res, ref)
     ms, launches = h.last_kernel_ms()
     assert launches >= 1
+
+
+def _tie_heavy(kind, n, d, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "duplicates":      # every vector appears twice (distinct ids): all distances tie pairwise
+        base = rng.random((n // 2, d), dtype=np.float32)
+        X = np.concatenate([base, base])[rng.permutation(n)]
+    else:                         # small-integer grid (tests/filtertest.rs:229-241 style): few distinct distances
+        X = rng.integers(0, 4, (n, d)).astype(np.float32)
+    return np.ascontiguousarray(X)
+
+
+@pytest.mark.parametrize("kind,dist", [("duplicates", "DistL2"), ("grid", "DistL2"), ("grid", "DistL1"), ("duplicates", "DistCosine")])
+def test_strict_ties_match_the_reference_heap_order(native, oracle, tmp_path, kind, dist):
+    """With EQUAL f32 distances the reference's answer depends on its BinaryHeaps' internal order.  The fast
+    kernel flags such queries; the strict replay emulates both heaps literally and must agree with the
+    oracle (which restates Rust's BinaryHeap) on ids, not only on distances."""
+    n, d = 1200, 6
+    X = _tie_heavy(kind, n, d, 77)
+    o = oracle.OracleHnsw(8, n, 16, 40, dist)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "ties")
+    h = native.HnswIo(tmp_path, "ties").load_hnsw(dist)
+    h.upload(0)
+    Q = _tie_heavy(kind, 200, d, 78)
+    ref = o.parallel_search(Q, 10, 32)
+    h.set_strict_ties(True)
+    res = h.parallel_search_flat(Q, 10, 32)
+    assert h.last_tie_count() > 20          # the data really produces ties
+    assert_same(res, ref)
+    # fast mode alone: same distances (as sorted lists), ids may be permuted among equals
+    h.set_strict_ties(False)
+    fast = h.parallel_search_flat(Q, 10, 32)
+    assert np.array_equal(fast.counts, ref.counts)
+    agree = np.mean([np.array_equal(fast.dists[i, :c], ref.dists[i, :c]) for i, c in enumerate(ref.counts)])
+    assert agree > 0.9
