@@ -751,20 +751,34 @@ typedef unsigned long long hent_t;
 __device__ __forceinline__ hent_t hmake(float key, uint32_t id) { return ((hent_t)__float_as_uint(key) << 32) | id; }
 __device__ __forceinline__ float hkey(hent_t e) { return __uint_as_float((uint32_t)(e >> 32)); }
 __device__ __forceinline__ uint32_t hid(hent_t e) { return (uint32_t)e; }
-__device__ __forceinline__ hent_t hload(const hent_t* H, uint32_t i) {
-    return __hip_atomic_load(H + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// A heap array: entries [0, lds_cap) live in LDS (the top levels, touched by every operation), the rest in
+// the workgroup's global scratch slice (L1-bypassing relaxed agent-scope accesses, served by the L2).
+struct HeapMem {
+    hent_t* lds;
+    hent_t* glb;
+    uint32_t lds_cap;
+};
+__device__ __forceinline__ hent_t hload(const HeapMem& H, uint32_t i) {
+    if (i < H.lds_cap) return H.lds[i];
+    return __hip_atomic_load(H.glb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void hstore(hent_t* H, uint32_t i, hent_t v) {
-    __hip_atomic_store(H + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void hstore(const HeapMem& H, uint32_t i, hent_t v) {
+    if (i < H.lds_cap) H.lds[i] = v;
+    else __hip_atomic_store(H.glb + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void hfence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// orders the stores of one heap operation before the loads of the next (single wave: LDS is in order,
+// global stores are waited for)
+__device__ __forceinline__ void hfence() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ hent_t readlane_h(hent_t v, int lane) {
     const uint32_t lo = readlane_u((uint32_t)v, lane), hi = readlane_u((uint32_t)(v >> 32), lane);
     return ((hent_t)hi << 32) | lo;
 }
 
 // BinaryHeap::push: data.push(item); sift_up(0, old_len): while pos > 0 { if elt <= data[parent] break; move parent down }
-__device__ __forceinline__ void heap_push(hent_t* H, uint32_t& len, hent_t item, int lane) {
+__device__ __forceinline__ void heap_push(const HeapMem& H, uint32_t& len, hent_t item, int lane) {
     const uint32_t pos = len;
     len += 1;
     // ancestor j of pos is ((pos+1) >> j) - 1
@@ -783,7 +797,7 @@ __device__ __forceinline__ void heap_push(hent_t* H, uint32_t& len, hent_t item,
 // Greater-child path from the root of H[0..end): at a node with two children take the right one when
 // data[left] <= data[right], with only a left child take it.  Returns the number m of path nodes below the
 // root; lane j (1..m) receives the j-th node's index and entry, lane 0 index 0.
-__device__ __forceinline__ int heap_chase(const hent_t* H, uint32_t end, int lane, uint32_t& my_pos, hent_t& my_ent) {
+__device__ __forceinline__ int heap_chase(const HeapMem& H, uint32_t end, int lane, uint32_t& my_pos, hent_t& my_ent) {
     int m = 0;
     uint32_t p = 0;
     my_pos = 0;
@@ -820,7 +834,7 @@ __device__ __forceinline__ int heap_chase(const hent_t* H, uint32_t end, int lan
 }
 
 // BinaryHeap::pop: swap-remove the root with the last element, sift_down_to_bottom(0), then sift_up.
-__device__ __forceinline__ hent_t heap_pop(hent_t* H, uint32_t& len, int lane) {
+__device__ __forceinline__ hent_t heap_pop(const HeapMem& H, uint32_t& len, int lane) {
     const hent_t last = hload(H, len - 1u);
     len -= 1;
     if (len == 0u) return last;
@@ -839,7 +853,7 @@ __device__ __forceinline__ hent_t heap_pop(hent_t* H, uint32_t& len, int lane) {
 }
 
 // sift_down_range(0, end) of into_sorted_vec: descend along the greater child, stop as soon as elt >= child
-__device__ __forceinline__ void heap_sift_down_range(hent_t* H, uint32_t end, int lane) {
+__device__ __forceinline__ void heap_sift_down_range(const HeapMem& H, uint32_t end, int lane) {
     const hent_t elt = hload(H, 0u);
     uint32_t my_pos;
     hent_t my_ent;
@@ -856,6 +870,8 @@ struct ExactArgs {
     hent_t* heaps;        // [gridDim.x][heap_stride]: return_points (ef + 2 entries) then candidate_points
     uint64_t heap_stride; // entries per workgroup
     uint32_t cand_cap;    // capacity of candidate_points
+    uint32_t r_lds_cap;   // entries of return_points kept in LDS
+    uint32_t cand_lds;    // entries of candidate_points kept in LDS
 };
 
 template <int METRIC>
@@ -865,8 +881,12 @@ __global__ __launch_bounds__(64) void hnsw_search_exact_kernel(DeviceIndexView i
     uint32_t* ids_lds = reinterpret_cast<uint32_t*>(lds_raw + TILE_BYTES);
     const int lane = (int)threadIdx.x;
     uint32_t* bitmap = a.bitmap + (size_t)blockIdx.x * a.bitmap_words;
-    hent_t* R = x.heaps + (size_t)blockIdx.x * x.heap_stride;
-    hent_t* Cq = R + (a.ef + 2u);
+    // LDS: [tile][ids][R heap: ef+2 entries][candidate heap: first cand_lds entries]
+    hent_t* lds_heaps = reinterpret_cast<hent_t*>(lds_raw + TILE_BYTES + IDS_BYTES);
+    hent_t* glb = x.heaps + (size_t)blockIdx.x * x.heap_stride;
+    const uint32_t r_lds = a.ef + 2u <= x.r_lds_cap ? a.ef + 2u : x.r_lds_cap;
+    const HeapMem R{lds_heaps, glb, r_lds};
+    const HeapMem Cq{lds_heaps + r_lds, glb + (a.ef + 2u), x.cand_lds};
 
     for (;;) {
         uint32_t wi = 0;
@@ -964,10 +984,13 @@ __global__ __launch_bounds__(64) void hnsw_search_exact_kernel(DeviceIndexView i
             uint32_t end = lenR;
             while (end > 1u) {
                 end -= 1;
-                if (lane == 0) {
+                {
                     const hent_t r0 = hload(R, 0u), re = hload(R, end);
-                    hstore(R, 0u, re);
-                    hstore(R, end, r0);
+                    hfence();
+                    if (lane == 0) {
+                        hstore(R, 0u, re);
+                        hstore(R, end, r0);
+                    }
                 }
                 hfence();
                 heap_sift_down_range(R, end, lane);
@@ -1380,8 +1403,12 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         x.heaps = static_cast<hent_t*>(d_heaps_);
         x.heap_stride = heap_stride;
         x.cand_cap = (uint32_t)cand_cap;
+        // heaps' top levels in LDS: up to ~56 KiB per workgroup (the exact replay is latency-, not occupancy-bound)
+        const uint64_t lds_budget = 56 * 1024 - (TILE_BYTES + IDS_BYTES);
+        x.r_lds_cap = (uint32_t)std::min<uint64_t>(ef + 2, lds_budget / 2 / sizeof(hent_t));
+        x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
         HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
-        const size_t lds = TILE_BYTES + IDS_BYTES;
+        const size_t lds = TILE_BYTES + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
         switch (dist_) {
             case DIST_L2: hipLaunchKernelGGL(hnsw_search_exact_kernel<DIST_L2>, dim3(grid), dim3(64), lds, stream, v_, a, x); break;
             case DIST_COSINE: hipLaunchKernelGGL(hnsw_search_exact_kernel<DIST_COSINE>, dim3(grid), dim3(64), lds, stream, v_, a, x); break;
