@@ -199,6 +199,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
+    main_ms = []
 
     def step():
         rc = lib.hnswgpu_search_batch_device(index.handle, Qd.data_ptr(), nq_local, d, k, ef, out_ids.data_ptr(),
@@ -208,6 +209,7 @@ def main():
             raise RuntimeError(H._native.last_error())
         ms, _ = index.last_kernel_ms()  # HIP events on the launch stream, inside the library
         kernel_ms.append(ms)
+        main_ms.append(index.last_search_kernel_ms())
         if world > 1:  # the only exchange on this path: gather of the answers (RCCL over xGMI)
             dist_pg.all_gather_into_tensor(gathered_ids, out_ids.to(coll_dev))
             dist_pg.all_gather_into_tensor(gathered_dists, out_dists.to(coll_dev))
@@ -220,6 +222,7 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
+    main_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -268,7 +271,10 @@ def main():
     n_dist, n_expand, n_ids = int(st[:, 0].sum()), int(st[:, 1].sum()), int(st[:, 2].sum())
     # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded
     alg_bytes = n_dist * d * 4 + n_ids * 4 + n_expand * 8 + nq_local * (d * 4 + k * 12)
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    # the dominant kernel is hnsw_search_kernel; the exact replay of tie-affected queries (strict ties)
+    # is a second, small kernel whose time is part of `value` but not of this kernel's roofline
+    k_ms = float(np.mean(main_ms)) if main_ms else float("nan")
+    all_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -282,6 +288,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_ms, 4),
+                "all_kernels_ms": round(all_ms, 4), "tie_replayed_queries": int((st[:, 3] == 3).sum()),
                 "launches_per_step": index.last_kernel_ms()[1],
                 "per_query": {"n_dist": n_dist / nq_local, "n_expand": n_expand / nq_local,
                               "n_ids_read": n_ids / nq_local, "bytes": alg_bytes / nq_local,

@@ -89,6 +89,7 @@ SYMBOLS = {
     "hnswgpu_search_batch": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
     "hnswgpu_search_batch_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hnswgpu_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "hnswgpu_last_search_kernel_ms": (_I, [_VP, C.POINTER(C.c_double)]),
     "hnswgpu_set_strict_ties": (_I, [_VP, _I]),
     "hnswgpu_last_tie_count": (_I, [_VP, C.POINTER(C.c_uint32)]),
     "hnswgpu_eval_distances": (_I, [_I, _VP, _VP, _U64, _U64, _VP]),

@@ -203,6 +203,11 @@ class Hnsw:
         _check(self._lib.hnswgpu_file_dump(self._h, str(path).encode(), file_basename.encode()))
         return file_basename
 
+    def last_search_kernel_ms(self):
+        ms = C.c_double()
+        _check(self._lib.hnswgpu_last_search_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def set_strict_ties(self, on=True):
         """Extension: replay tie-affected queries with a literal emulation of the reference's heaps."""
         _check(self._lib.hnswgpu_set_strict_ties(self._h, int(bool(on))))

@@ -278,6 +278,12 @@ int hnswgpu_last_kernel_ms(const hnswgpu_index* cidx, double* ms, uint32_t* laun
     return HNSWGPU_OK;
 }
 
+int hnswgpu_last_search_kernel_ms(const hnswgpu_index* cidx, double* ms) {
+    hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
+    if (!idx || !idx->dev || !ms) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
+    *ms = idx->dev->last_main_kernel_ms();
+    return HNSWGPU_OK;
+}
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on) {
     if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
     std::lock_guard<std::mutex> g(idx->mu);

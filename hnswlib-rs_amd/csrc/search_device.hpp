@@ -52,6 +52,7 @@ public:
     bool strict_ties() const { return strict_ties_; }
     uint32_t last_ties() const { return last_ties_; }
     double last_kernel_ms() const { return last_ms_; }
+    double last_main_kernel_ms() const { return last_main_ms_; }
     uint32_t last_launches() const { return last_launches_; }
 
 private:
@@ -79,13 +80,16 @@ private:
     uint64_t hostio_cap_q_ = 0, hostio_cap_k_ = 0, hostio_cap_n_ = 0;
     void* ev_start_ = nullptr;
     void* ev_stop_ = nullptr;
+    void* ev_mid_ = nullptr;
     void* d_tie_ = nullptr;       uint64_t tie_cap_ = 0;      // queries flagged with an exact distance tie
     void* d_heaps_ = nullptr;     uint64_t heaps_cap_ = 0;    // scratch of the exact replay
+    void* d_oplog_ = nullptr;     void* d_cand_ = nullptr; uint64_t strict_cap_ = 0;  // in-launch exact switch
     bool strict_ties_ = true;
     uint32_t last_ties_ = 0;
     uint64_t adapt_ef_ = 0;       // visited-table sizing learned from previous batches with this ef
     uint32_t adapt_tbits_ = 0;
     double last_ms_ = 0.0;
+    double last_main_ms_ = 0.0;
     uint32_t last_launches_ = 0;
 };
 

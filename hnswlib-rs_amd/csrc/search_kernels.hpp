@@ -1,0 +1,77 @@
+// search_kernels.hpp -- plain argument structs and launch entry points shared by the host driver
+// (search_device.hip) and the per-metric kernel translation units (search_kernels_<metric>.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "search_device.hpp"
+
+namespace hnswgpu {
+
+constexpr uint32_t EXPANDED = 0x80000000u;  // flag bit on a result entry whose neighbour list was read
+constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
+// visited-set representations (see visit_*)
+constexpr int TABLE_LDS_CELL16 = 0;
+constexpr int TABLE_LDS_CELL32 = 1;
+constexpr int TABLE_GLOBAL_BITMAP = 2;
+
+// LDS carve (bytes) in front of the visited table
+constexpr uint32_t TILE_ROWS = 16;                       // rows transposed per sub-batch
+constexpr uint32_t TILE_PITCH = TILE_ROWS + 1;           // float4 units; +1 keeps ds_write_b128 conflict-free
+constexpr uint32_t TILE_BYTES = 2 * 8 * TILE_PITCH * 16; // two buffers of 8 chunks x 16 B per row and pass
+constexpr uint32_t IDS_BYTES = 64 * 4;
+
+typedef unsigned long long hent_t;  // heap / log entry: {key f32 (high), id u32 (low)}
+
+struct SearchArgs {
+    const float* queries;   // [nq][row_stride], zero padded
+    const uint32_t* qlist;  // optional: indices of the queries to run (retry pass), else nullptr
+    uint32_t nq;            // number of work items
+    uint32_t k;
+    uint32_t ef;            // already max(ef_arg, k)
+    uint32_t tbits;         // visited table = 1 << tbits cells
+    uint32_t idbits;        // ceil(log2(n))
+    uint32_t restbits;      // CELL16: idbits - tbits bits of the mixed id kept in the cell
+    uint32_t* work_counter; // persistent-grid work queue head
+    uint32_t* overflow_count;
+    uint32_t* retry_out;    // queries whose visited table overflowed
+    uint32_t* bitmap;       // [bitmap_blocks][bitmap_words]: per-workgroup visited bitmaps in HBM
+    uint32_t bitmap_words;
+    uint32_t bitmap_blocks; // workgroups with blockIdx.x < bitmap_blocks own a slice
+    uint32_t* tie_list;     // strict ties: queries that met an exact distance tie (count at overflow_count + 3)
+    hent_t* oplog;          // strict ties: [gridDim.x][oplog_cap] per-workgroup log of heap operations
+    uint32_t oplog_cap;
+    hent_t* cand_scratch;   // strict ties: [gridDim.x][cand_cap] candidate heap beyond its LDS part
+    uint32_t cand_cap;
+    uint64_t* out_ids;
+    float* out_dists;
+    uint8_t* out_layer;
+    int32_t* out_rank;
+    uint32_t* out_counts;
+    uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used, 0
+};
+
+struct ExactArgs {
+    hent_t* heaps;        // [gridDim.x][heap_stride]: return_points (ef + 2 entries) then candidate_points
+    uint64_t heap_stride; // entries per workgroup
+    uint32_t cand_cap;    // capacity of candidate_points
+    uint32_t r_lds_cap;   // entries of return_points kept in LDS
+    uint32_t cand_lds;    // entries of candidate_points kept in LDS
+};
+
+// One translation unit per metric instantiates the kernels (keeps the build parallel and the objects small).
+struct KernelSet {
+    // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (heap-operation log +
+    // in-launch switch to literal heaps) or lean
+    hipError_t (*launch_search)(int slots, int table, bool strict, uint32_t grid, size_t lds, hipStream_t stream,
+                                const DeviceIndexView& ix, const SearchArgs& a);
+    hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);
+    hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
+                               const SearchArgs& a, const ExactArgs& x);
+    hipError_t (*launch_eval_pairs)(uint32_t blocks, const float* a, const float* b, float* out, uint32_t n, uint32_t row_stride);
+};
+const KernelSet& kernels_l2();
+const KernelSet& kernels_cosine();
+const KernelSet& kernels_dot();
+const KernelSet& kernels_l1();
+
+}  // namespace hnswgpu

@@ -152,6 +152,8 @@ int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
 /* Timing of the kernels of the last search call on this index, measured with HIP events on
  * the launch stream: total milliseconds and number of launches (retries included).        */
 int hnswgpu_last_kernel_ms(const hnswgpu_index* idx, double* ms, uint32_t* launches);
+/* Same, but only up to the end of the search kernel proper (excludes the exact replay of tied queries). */
+int hnswgpu_last_search_kernel_ms(const hnswgpu_index* idx, double* ms);
 
 /* Distance<f32>::eval evaluated ON THE DEVICE for n pairs (a[i], b[i]) of dimension d, in
  * the same arithmetic as the search kernel (host buffers).  For arithmetic parity tests.  */
