@@ -410,7 +410,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
         HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
         const size_t lds = TILE_BYTES + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
-        const int ns = ef + 1 <= 64 ? 1 : ef + 1 <= 128 ? 2 : 0;  // return_points in VGPRs when it fits
+        const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
         HIP_TRY(kernel_set(dist_).launch_exact(ns, grid, lds, stream, v_, a, x));
         ++launches;
         uint32_t ctrl2[2] = {0, 0};
