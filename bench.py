@@ -235,6 +235,29 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq_total * args.steps / elapsed
+    stats_strict = stats.clone()
+
+    # for reference: the same steps with strict ties OFF (equal distances ordered by arrival, queries flagged)
+    fast_qps = None
+    if lib.hnswgpu_set_strict_ties(index.handle, 0) == 0:
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist_pg.all_reduce(t, op=dist_pg.ReduceOp.MAX)
+            el = float(t.item())
+        fast_qps = nq_total * args.steps / el
+        lib.hnswgpu_set_strict_ties(index.handle, 1)
+        step()   # leave the strict answers in the output buffers for the recall / parity checks below
+        fence()
+        kernel_ms[:] = kernel_ms[:args.steps]
+        main_ms[:] = main_ms[:args.steps]
+    stats.copy_(stats_strict)
 
     # ---------------------------------------------------------------- recall vs exact brute force
     res_ids = out_ids.cpu().numpy()
@@ -322,7 +345,8 @@ def main():
         # queries are reported separately.
         gpu_ids = res_ids[:sample].astype(np.uint64)
         gpu_bits = out_dists.cpu().numpy()[:sample].view(np.uint32)
-        tie_flag = st[:sample, 3] == 2
+        tie_flag = (st[:sample, 3] == 2) | (st[:sample, 3] == 3)
+        exact_used = st[:sample, 3] == 3
         row_ids_ok = np.all(r.ids == gpu_ids, axis=1) & (r.counts == cnt[:sample].astype(np.uint32))
         row_bits_ok = np.all(r.dists.view(np.uint32) == gpu_bits, axis=1)
         parity = {"queries_checked": int(sample),
@@ -330,6 +354,7 @@ def main():
                   "tie_free_ids_identical": bool(row_ids_ok[~tie_flag].all()),
                   "tie_free_f32_distance_bits_identical": bool(row_bits_ok[~tie_flag].all()),
                   "queries_with_exact_distance_tie": int(tie_flag.sum()),
+                  "tied_queries_resolved_with_literal_heaps": int(exact_used.sum()),
                   "tied_queries_ids_identical": int(row_ids_ok[tie_flag].sum()),
                   "tied_queries_distance_bits_identical": int(row_bits_ok[tie_flag].sum())}
         cpu_baseline = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": best_threads, "kind": "port",
@@ -349,6 +374,8 @@ def main():
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
                        "queries_total": nq_total, "graph": "replicated per GPU", "exchange": "all_gather of answers (RCCL)" if world > 1 else "none"},
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
+            "strict_ties": {"on": True, "note": "queries that meet an exact f32 distance tie switch to a literal emulation of the reference's BinaryHeaps (DESIGN.md section 6)",
+                            "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_vs_oracle": parity,
