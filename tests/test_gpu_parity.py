@@ -176,3 +176,35 @@ def test_strict_ties_match_the_reference_heap_order(native, oracle, tmp_path, ki
     assert np.array_equal(fast.counts, ref.counts)
     agree = np.mean([np.array_equal(fast.dists[i, :c], ref.dists[i, :c]) for i, c in enumerate(ref.counts)])
     assert agree > 0.9
+
+
+def test_reference_style_c_symbols_search(native, oracle, tmp_path, monkeypatch):
+    """search_neighbours_f32 / parallel_search_neighbours_f32 (src/libext.rs:728-767, :205-254): same structs,
+    same answers as the oracle."""
+    import ctypes as C
+    lib = native.lib()
+    X = uniform(1500, 12, 31)
+    o = oracle.OracleHnsw(12, 1500, 16, 60, "DistL2")
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "ffi")
+    monkeypatch.chdir(tmp_path)
+    io = lib.get_hnswio(3, b"ffi")
+    api = lib.load_hnswdump_f32_DistL2(io)
+    assert api
+    Q = uniform(40, 12, 32)
+    ref = o.parallel_search(Q, 6, 30)
+    ptrs = (C.c_void_p * 40)(*[Q[i].ctypes.data for i in range(40)])
+    res = lib.parallel_search_neighbours_f32(api, 40, 12, ptrs, 6, 30)
+    assert res and res.contents.len == 40
+    for i in range(40):
+        nb = res.contents.ptr[i]
+        assert nb.nbgh == ref.counts[i]
+        for j in range(nb.nbgh):
+            assert nb.neighbours[j].id == ref.ids[i, j] and nb.neighbours[j].d == ref.dists[i, j]
+    one = lib.search_neighbours_f32(api, 12, Q[3].ctypes.data, 6, 30)
+    assert one and one.contents.nbgh == ref.counts[3]
+    assert [one.contents.neighbours[j].id for j in range(6)] == ref.ids[3].tolist()
+    lib.hnswgpu_free_neighbourhood(one)
+    lib.hnswgpu_free_neighbourhood_vec(res)
+    lib.drop_hnsw_f32(api)
+    lib.hnswgpu_free_hnswio(io)
