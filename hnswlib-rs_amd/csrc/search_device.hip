@@ -79,7 +79,7 @@ DeviceIndex::~DeviceIndex() { release(); }
 void DeviceIndex::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
     void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_qpad_, &d_ctrl_, &d_retry_[0], &d_retry_[1],
-                     &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_oplog_, &d_cand_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
+                     &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_cand_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
     for (void** p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (ev_start_) { (void)hipEventDestroy((hipEvent_t)ev_start_); ev_start_ = nullptr; }
@@ -323,22 +323,21 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         }
         a.tie_list = strict_ties_ ? static_cast<uint32_t*>(d_tie_) : nullptr;
         if (strict_kernel) {
-            // per-workgroup heap-operation log + candidate-heap scratch for the in-launch switch to exact heaps
+            // per-workgroup scratch for the part of candidate_points that does not fit in LDS
             const uint32_t cap = 8192;
             const uint64_t need = (uint64_t)grid * cap * sizeof(hent_t);
             if (need > strict_cap_) {
-                if (d_oplog_) (void)hipFree(d_oplog_);
                 if (d_cand_) (void)hipFree(d_cand_);
-                d_oplog_ = d_cand_ = nullptr;
+                d_cand_ = nullptr;
                 strict_cap_ = 0;
-                HIP_TRY(hipMalloc(&d_oplog_, need));
                 HIP_TRY(hipMalloc(&d_cand_, need));
                 strict_cap_ = need;
             }
-            a.oplog = static_cast<hent_t*>(d_oplog_);
-            a.oplog_cap = cap;
             a.cand_scratch = static_cast<hent_t*>(d_cand_);
             a.cand_cap = cap;
+            // most queries of the previous batch met a tie (integer-valued data does that): skip the first attempt
+            a.exact_first = (adapt_exact_ef_ == ef && adapt_exact_first_) ? 1u : 0u;
+            if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;
         }
         HIP_TRY(hipMemsetAsync(d_ctrl_, 0, launches == 0 ? 32 : 16, stream));  // the tie list spans relaunches
         HIP_TRY(ks.launch_search(slots, table, strict_kernel, grid, lds, stream, v_, a));
@@ -348,7 +347,11 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         HIP_TRY(hipMemcpyAsync(ctrl, d_ctrl_, 24, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         n_ties = ctrl[4];        // flagged for the replay kernel (cumulative over relaunches)
-        n_converted = ctrl[5];   // switched to exact heaps inside the launch
+        n_converted = ctrl[5];   // needed the literal heaps inside the launch
+        if (launches == 1 && strict_kernel && nq >= 256) {
+            adapt_exact_ef_ = ef;
+            adapt_exact_first_ = (uint64_t)n_converted * 2 > nq;
+        }
         if (launches == 1 && table != TABLE_GLOBAL_BITMAP && !env_forced && nq >= 256) {
             // Table sizing feedback for the next batch: grow when more than ~1 query in 8 had to move to the
             // HBM bitmap, shrink when a half-size table would have overflowed for fewer than 1 in 32.

@@ -83,7 +83,8 @@ private:
     void* ev_mid_ = nullptr;
     void* d_tie_ = nullptr;       uint64_t tie_cap_ = 0;      // queries flagged with an exact distance tie
     void* d_heaps_ = nullptr;     uint64_t heaps_cap_ = 0;    // scratch of the exact replay
-    void* d_oplog_ = nullptr;     void* d_cand_ = nullptr; uint64_t strict_cap_ = 0;  // in-launch exact switch
+    void* d_cand_ = nullptr;      uint64_t strict_cap_ = 0;   // in-launch literal heaps: candidate_points beyond LDS
+    uint64_t adapt_exact_ef_ = 0; bool adapt_exact_first_ = false;  // previous batch: did most queries meet a tie?
     bool strict_ties_ = true;
     uint32_t last_ties_ = 0;
     uint64_t adapt_ef_ = 0;       // visited-table sizing learned from previous batches with this ef

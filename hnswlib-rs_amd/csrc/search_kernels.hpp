@@ -38,10 +38,9 @@ struct SearchArgs {
     uint32_t bitmap_words;
     uint32_t bitmap_blocks; // workgroups with blockIdx.x < bitmap_blocks own a slice
     uint32_t* tie_list;     // strict ties: queries that met an exact distance tie (count at overflow_count + 3)
-    hent_t* oplog;          // strict ties: [gridDim.x][oplog_cap] per-workgroup log of heap operations
-    uint32_t oplog_cap;
     hent_t* cand_scratch;   // strict ties: [gridDim.x][cand_cap] candidate heap beyond its LDS part
     uint32_t cand_cap;
+    uint32_t exact_first;   // strict ties: skip the sorted-array attempt, answer every query with the literal heaps
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
@@ -60,8 +59,8 @@ struct ExactArgs {
 
 // One translation unit per metric instantiates the kernels (keeps the build parallel and the objects small).
 struct KernelSet {
-    // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (heap-operation log +
-    // in-launch switch to literal heaps) or lean
+    // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (queries that meet an
+    // exact f32 tie are searched again with literal heaps inside the launch) or lean
     hipError_t (*launch_search)(int slots, int table, bool strict, uint32_t grid, size_t lds, hipStream_t stream,
                                 const DeviceIndexView& ix, const SearchArgs& a);
     hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);

@@ -208,3 +208,25 @@ def test_reference_style_c_symbols_search(native, oracle, tmp_path, monkeypatch)
     lib.hnswgpu_free_neighbourhood_vec(res)
     lib.drop_hnsw_f32(api)
     lib.hnswgpu_free_hnswio(io)
+
+
+EDGE_CASES = [
+    # n, d, M, ef_c, dist, k, ef, nq     what it exercises
+    (1500, 3, 8, 40, "DistL2", 5, 20, 100),        # d < 4: one padded chunk
+    (1500, 33, 8, 40, "DistL2", 5, 20, 100),       # row_stride 64: two passes, tail of zeros
+    (1200, 100, 8, 40, "DistCosine", 5, 20, 80),   # 4 passes, d not a multiple of 32, f64 sums
+    (1200, 200, 8, 40, "DistDot", 5, 20, 80),      # 7 passes: one full group of 4 + remainder 3
+    (2500, 16, 40, 100, "DistL2", 10, 50, 150),    # 2M = 80 neighbour ids per row: multi-batch id rows (> 64)
+    (2500, 16, 100, 150, "DistL1", 10, 30, 100),   # 2M = 200: four id batches per expansion
+    (3000, 8, 12, 60, "DistL2", 10, 300, 100),     # ef = 300: 16 result slots per lane, memory return_points in replays
+    (3000, 8, 12, 60, "DistL2", 100, 1000, 60),    # ef = 1000, k = 100
+    (40, 8, 6, 20, "DistL2", 10, 64, 40),          # tiny index: fewer points than ef
+]
+
+
+@pytest.mark.parametrize("n,d,m,efc,dist,k,ef,nq", EDGE_CASES)
+def test_shape_edge_cases(native, oracle, tmp_path, n, d, m, efc, dist, k, ef, nq):
+    normalize = dist == "DistDot"
+    X, o, h = build_pair(native, oracle, tmp_path, n, d, m, efc, dist, seed=n + d + m, normalize=normalize)
+    Q = normalized(nq, d, 3) if normalize else uniform(nq, d, 3)
+    assert_same(h.parallel_search_flat(Q, k, ef), o.parallel_search(Q, k, ef))
