@@ -79,12 +79,14 @@ DeviceIndex::~DeviceIndex() { release(); }
 void DeviceIndex::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
     void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_qpad_, &d_ctrl_, &d_retry_[0], &d_retry_[1],
-                     &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_cand_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
+                     &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_cand_, &d_predist_, &d_order_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
     for (void** p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (ev_start_) { (void)hipEventDestroy((hipEvent_t)ev_start_); ev_start_ = nullptr; }
     if (ev_stop_) { (void)hipEventDestroy((hipEvent_t)ev_stop_); ev_stop_ = nullptr; }
     if (ev_mid_) { (void)hipEventDestroy((hipEvent_t)ev_mid_); ev_mid_ = nullptr; }
+    if (ev_ks_) { (void)hipEventDestroy((hipEvent_t)ev_ks_); ev_ks_ = nullptr; }
+    if (ev_ke_) { (void)hipEventDestroy((hipEvent_t)ev_ke_); ev_ke_ = nullptr; }
     ready_ = false;
 }
 
@@ -172,6 +174,11 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     ev_start_ = e0;
     ev_stop_ = e1;
     ev_mid_ = e2;
+    hipEvent_t e3, e4;
+    HIP_TRY(hipEventCreate(&e3));
+    HIP_TRY(hipEventCreate(&e4));
+    ev_ks_ = e3;
+    ev_ke_ = e4;
 
     v.vec = static_cast<const float*>(d_vec_);
     v.nbr0 = static_cast<const uint32_t*>(d_nbr0_);
@@ -196,6 +203,16 @@ int DeviceIndex::ensure_workspace(uint64_t nq, uint64_t /*k*/, std::string& err)
         d_tie_ = nullptr;
         HIP_TRY(hipMalloc(&d_tie_, nq * sizeof(uint32_t)));
         tie_cap_ = nq;
+    }
+    if (nq > sched_cap_) {
+        for (void** p : {&d_predist_, &d_order_}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        sched_cap_ = 0;
+        HIP_TRY(hipMalloc(&d_predist_, nq * sizeof(float)));
+        HIP_TRY(hipMalloc(&d_order_, nq * sizeof(uint32_t)));
+        sched_cap_ = nq;
     }
     if (nq > retry_cap_) {
         for (int i = 0; i < 2; ++i) {
@@ -258,14 +275,29 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (b >= 6 && b <= 14) { tbits = (uint32_t)b; env_forced = true; }
     }
     const uint32_t tbits_first = tbits;
-    const size_t lds_fixed = TILE_BYTES + IDS_BYTES;
+    const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
+    const size_t lds_fixed = tile_bytes + IDS_BYTES;
     int table = TABLE_LDS_CELL16;
     bool grown = false;
 
+    // Batch scheduling: the searches run in descending order of the (estimated) distance to the layer-0 entry point,
+    // long searches first (DESIGN.md "scheduling").  Small batches skip it (one launch, lowest latency).
+    const bool scheduled = nq >= 256 && !std::getenv("HNSWGPU_NO_SCHED");
+    if (scheduled) {
+        SearchArgs da{};
+        da.queries = static_cast<const float*>(d_qpad_);
+        da.nq = (uint32_t)nq;
+        da.work_counter = static_cast<uint32_t*>(d_ctrl_);
+        da.pre_dist = static_cast<float*>(d_predist_);
+        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 4, stream));
+        const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)num_cu_ * 24u);
+        HIP_TRY(kernel_set(dist_).launch_estimate(dgrid, stream, v_, da));
+        HIP_TRY(kernel_set(dist_).launch_order(stream, static_cast<const float*>(d_predist_), (uint32_t)nq, static_cast<uint32_t*>(d_order_)));
+    }
     uint32_t launches = 0;
     uint32_t work = (uint32_t)nq;
     uint32_t n_ties = 0, n_converted = 0;
-    const uint32_t* qlist = nullptr;
+    const uint32_t* qlist = scheduled ? static_cast<const uint32_t*>(d_order_) : nullptr;
     int pingpong = 0;
     SearchArgs last_args{};
     for (;;) {
@@ -283,9 +315,14 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             }
             a.tbits = tb;
         }
+        a.tile_bytes = tile_bytes;
         a.idbits = idbits;
         const KernelSet& ks = kernel_set(dist_);
         const bool strict_kernel = strict_ties_ && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
+        if (strict_kernel) {  // top levels of candidate_points for the queries that are answered by the literal heaps
+            a.cand_lds = 512;
+            lds += (size_t)a.cand_lds * sizeof(hent_t);
+        }
         int per_cu = 0;
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));
         if (per_cu < 1) per_cu = 1;
@@ -340,7 +377,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;
         }
         HIP_TRY(hipMemsetAsync(d_ctrl_, 0, launches == 0 ? 32 : 16, stream));  // the tie list spans relaunches
+        if (launches == 0) HIP_TRY(hipEventRecord((hipEvent_t)ev_ks_, stream));
         HIP_TRY(ks.launch_search(slots, table, strict_kernel, grid, lds, stream, v_, a));
+        if (launches == 0) HIP_TRY(hipEventRecord((hipEvent_t)ev_ke_, stream));
         last_args = a;
         ++launches;
         uint32_t ctrl[6] = {0, 0, 0, 0, 0, 0};
@@ -408,11 +447,11 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         x.heap_stride = heap_stride;
         x.cand_cap = (uint32_t)cand_cap;
         // heaps' top levels in LDS: up to ~56 KiB per workgroup (the exact replay is latency-, not occupancy-bound)
-        const uint64_t lds_budget = 56 * 1024 - (TILE_BYTES + IDS_BYTES);
+        const uint64_t lds_budget = 56 * 1024 - (tile_bytes + IDS_BYTES);
         x.r_lds_cap = (uint32_t)std::min<uint64_t>(ef + 2, lds_budget / 2 / sizeof(hent_t));
         x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
         HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
-        const size_t lds = TILE_BYTES + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
+        const size_t lds = tile_bytes + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
         const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
         HIP_TRY(kernel_set(dist_).launch_exact(ns, grid, lds, stream, v_, a, x));
         ++launches;
@@ -425,7 +464,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     HIP_TRY(hipEventSynchronize((hipEvent_t)ev_stop_));
     float ms = 0.f, ms_main = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev_start_, (hipEvent_t)ev_stop_));
-    HIP_TRY(hipEventElapsedTime(&ms_main, (hipEvent_t)ev_start_, (hipEvent_t)ev_mid_));
+    HIP_TRY(hipEventElapsedTime(&ms_main, (hipEvent_t)ev_ks_, (hipEvent_t)ev_ke_));  // first launch of the search kernel alone
     last_ms_ = ms;
     last_main_ms_ = ms_main;
     last_launches_ = launches;

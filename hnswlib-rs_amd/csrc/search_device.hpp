@@ -82,6 +82,9 @@ private:
     void* ev_stop_ = nullptr;
     void* ev_mid_ = nullptr;
     void* d_tie_ = nullptr;       uint64_t tie_cap_ = 0;      // queries flagged with an exact distance tie
+    void* d_predist_ = nullptr;   void* d_order_ = nullptr;   // batch scheduling (estimate pass)
+    uint64_t sched_cap_ = 0;
+    void* ev_ks_ = nullptr;       void* ev_ke_ = nullptr;     // around the first launch of the search kernel
     void* d_heaps_ = nullptr;     uint64_t heaps_cap_ = 0;    // scratch of the exact replay
     void* d_cand_ = nullptr;      uint64_t strict_cap_ = 0;   // in-launch literal heaps: candidate_points beyond LDS
     uint64_t adapt_exact_ef_ = 0; bool adapt_exact_first_ = false;  // previous batch: did most queries meet a tie?

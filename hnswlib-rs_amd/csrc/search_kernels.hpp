@@ -29,6 +29,7 @@ struct SearchArgs {
     uint32_t k;
     uint32_t ef;            // already max(ef_arg, k)
     uint32_t tbits;         // visited table = 1 << tbits cells
+    uint32_t tile_bytes;    // LDS bytes in front of the id buffer: transposing tile (cosine) or the staged query row
     uint32_t idbits;        // ceil(log2(n))
     uint32_t restbits;      // CELL16: idbits - tbits bits of the mixed id kept in the cell
     uint32_t* work_counter; // persistent-grid work queue head
@@ -40,12 +41,14 @@ struct SearchArgs {
     uint32_t* tie_list;     // strict ties: queries that met an exact distance tie (count at overflow_count + 3)
     hent_t* cand_scratch;   // strict ties: [gridDim.x][cand_cap] candidate heap beyond its LDS part
     uint32_t cand_cap;
+    uint32_t cand_lds;      // strict ties: entries of candidate_points kept in LDS (behind the visited table)
     uint32_t exact_first;   // strict ties: skip the sorted-array attempt, answer every query with the literal heaps
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
     int32_t* out_rank;
     uint32_t* out_counts;
+    float* pre_dist;        // hnsw_estimate_kernel: [nq] estimated distance to the layer-0 entry point (scheduling key)
     uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used, 0
 };
 
@@ -67,7 +70,15 @@ struct KernelSet {
     hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
                                const SearchArgs& a, const ExactArgs& x);
     hipError_t (*launch_eval_pairs)(uint32_t blocks, const float* a, const float* b, float* out, uint32_t n, uint32_t row_stride);
+    // batch scheduling: estimated distance of every query to its layer-0 entry point, then the queries in descending
+    // order of it
+    hipError_t (*launch_estimate)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const SearchArgs& a);
+    hipError_t (*launch_order)(hipStream_t stream, const float* keys, uint32_t n, uint32_t* order);
 };
+// LDS in front of the id buffer: cosine transposes row tiles through it, the other metrics keep the query there
+inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
+    return metric == DIST_COSINE ? TILE_BYTES : ((row_stride * 4u + 15u) & ~15u);
+}
 const KernelSet& kernels_l2();
 const KernelSet& kernels_cosine();
 const KernelSet& kernels_dot();
