@@ -287,9 +287,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         SearchArgs da{};
         da.queries = static_cast<const float*>(d_qpad_);
         da.nq = (uint32_t)nq;
-        da.work_counter = static_cast<uint32_t*>(d_ctrl_);
         da.pre_dist = static_cast<float*>(d_predist_);
-        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 4, stream));
         const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)num_cu_ * 24u);
         HIP_TRY(kernel_set(dist_).launch_estimate(dgrid, stream, v_, da));
         HIP_TRY(kernel_set(dist_).launch_order(stream, static_cast<const float*>(d_predist_), (uint32_t)nq, static_cast<uint32_t*>(d_order_)));

@@ -135,7 +135,8 @@ int hnswgpu_search_batch(const hnswgpu_index* idx, const float* queries, uint64_
  * before returning (the visited-set overflow check needs one 4-byte read-back).
  * d_stats may be NULL, else uint32[nq*8] per query = {n_dist, n_expand, n_ids_read, status,
  * t_start, t_end (device wall clock, 10 ns ticks), used_hbm_bitmap, 0}.
- * status: 0 ok; 2 ok, but an exact f32 distance tie was met (see DESIGN.md "ties").           */
+ * status: 0 ok; 2 ok, but an exact f32 distance tie was met and strict ties are off; 3 ok, answered
+ * by the literal heaps (strict ties; see DESIGN.md "ties").                                       */
 int hnswgpu_search_batch_device(const hnswgpu_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
                                 uint64_t k, uint64_t ef, uint64_t* d_out_ids, float* d_out_dists,
                                 uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
@@ -143,9 +144,10 @@ int hnswgpu_search_batch_device(const hnswgpu_index* idx, const float* d_queries
 
 /* Ties.  Two EQUAL f32 distances make the reference's answer depend on the internal order of Rust's
  * BinaryHeap.  The fast kernel orders equals by arrival and flags such queries (stats status 2);
- * with strict ties ON (default; env HNSWGPU_STRICT_TIES=0 or this call turns it off) the flagged
- * queries are re-run by a second kernel that emulates both heaps literally, so that ids match the
- * reference bit for bit also under ties.  hnswgpu_last_tie_count: flagged queries of the last call. */
+ * with strict ties ON (default; env HNSWGPU_STRICT_TIES=0 or this call turns it off) such a query is
+ * searched again, inside the same launch, with a literal emulation of both heaps (stats status 3), so
+ * that ids match the reference bit for bit also under ties.  hnswgpu_last_tie_count: queries of the
+ * last call that met a tie (flagged, or answered by the literal heaps).                              */
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on);
 int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
 

@@ -141,6 +141,22 @@ def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, monkeyp
     assert launches >= 1
 
 
+def test_batch_scheduling_and_exact_first_do_not_change_answers(native, oracle, tmp_path, monkeypatch):
+    """Batches of >= 256 queries are searched longest-first (estimate + ordering kernels); HNSWGPU_NO_SCHED turns
+    that off, HNSWGPU_EXACT_FIRST=1 answers every query with the literal heaps from the start (what the library does
+    by itself when most queries of the previous batch met a tie).  Same answers as the oracle in every mode."""
+    X, o, h = build_pair(native, oracle, tmp_path, 6000, 48, 16, 100, "DistL2", seed=33)
+    Q = uniform(700, 48, 34)
+    ref = o.parallel_search(Q, 10, 64)
+    assert_same(h.parallel_search_flat(Q, 10, 64), ref)
+    monkeypatch.setenv("HNSWGPU_NO_SCHED", "1")
+    assert_same(h.parallel_search_flat(Q, 10, 64), ref)
+    monkeypatch.delenv("HNSWGPU_NO_SCHED")
+    monkeypatch.setenv("HNSWGPU_EXACT_FIRST", "1")
+    assert_same(h.parallel_search_flat(Q, 10, 64), ref)
+    assert h.last_tie_count() <= 700
+
+
 def _tie_heavy(kind, n, d, seed):
     rng = np.random.default_rng(seed)
     if kind == "duplicates":      # every vector appears twice (distinct ids): all distances tie pairwise
