@@ -159,4 +159,36 @@ int orc_heap_exercise(const float* vals, const int32_t* tags, size_t n, int mode
     ORC_CATCH(-1)
 }
 
+// Scripted BinaryHeap driver: step i pushes (vals[i], tags[i]) when is_pop[i] == 0, else pops.  out_* receive
+// the popped entries in order (returns their number through *npopped); sorted_* receive into_sorted_vec of what
+// is left (returns its length).  Used to check the device's lane-parallel heap algorithms (emulated in Python,
+// tests/test_heap_algorithms.py) against the literal restatement on interleaved pushes and pops with ties.
+int orc_heap_script(const float* vals, const int32_t* tags, const uint8_t* is_pop, size_t n, float* out_vals,
+                    int32_t* out_tags, size_t* npopped, float* sorted_vals, int32_t* sorted_tags) {
+    ORC_TRY
+    RustBinaryHeap hp;
+    float dummy[1] = {0.f};
+    size_t np = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (is_pop[i]) {
+            PWO x;
+            if (!hp.pop(x)) continue;
+            out_vals[np] = x->dist_to_ref;
+            out_tags[np] = x->point_ref->p_id.rank;
+            ++np;
+        } else {
+            auto p = std::make_shared<Point>(dummy, 1, (size_t)tags[i], PointId{0, tags[i]});
+            hp.push(std::make_shared<PointWithOrder>(p, vals[i]));
+        }
+    }
+    *npopped = np;
+    auto v = hp.into_sorted_vec();
+    for (size_t i = 0; i < v.size(); ++i) {
+        sorted_vals[i] = v[i]->dist_to_ref;
+        sorted_tags[i] = v[i]->point_ref->p_id.rank;
+    }
+    return (int)v.size();
+    ORC_CATCH(-1)
+}
+
 }  // extern "C"

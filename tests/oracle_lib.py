@@ -63,6 +63,8 @@ def lib():
         L.orc_levels.argtypes = [C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_heap_exercise.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                         C.c_void_p]
+        L.orc_heap_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -195,3 +197,18 @@ def heap_exercise(vals, tags, mode, npop=0):
     if r < 0:
         raise RuntimeError(_err())
     return ov[:r], ot[:r]
+
+
+def heap_script(vals, tags, is_pop):
+    """Interleaved pushes / pops on the restated BinaryHeap; returns (popped_vals, popped_tags, sorted_vals, sorted_tags)."""
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    tags = np.ascontiguousarray(tags, dtype=np.int32)
+    is_pop = np.ascontiguousarray(is_pop, dtype=np.uint8)
+    n = len(vals)
+    ov, ot = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    sv, st = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    npop = C.c_size_t(0)
+    r = lib().orc_heap_script(_p(vals), _p(tags), _p(is_pop), n, _p(ov), _p(ot), C.byref(npop), _p(sv), _p(st))
+    if r < 0:
+        raise RuntimeError(_err())
+    return ov[:npop.value], ot[:npop.value], sv[:r], st[:r]
