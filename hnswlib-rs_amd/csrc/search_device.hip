@@ -1,18 +1,21 @@
-// search_device.hip -- CDNA4 (gfx950) kernels for the batched-search hot path of hnsw_rs and
-// the host driver that launches them.  Written for MI355X only: wave64, LDS, 8 XCDs.
+// search_device.hip -- host driver of the CDNA4 (gfx950) kernels for the batched-search hot path of hnsw_rs
+// (the device code is in search_kernels.inc, instantiated per metric).  Written for MI355X only: wave64, LDS.
 //
 // Reference path (file:line under /root/reference):
-//   Hnsw::parallel_search          src/hnsw.rs:1612-1635   -> one wavefront per query, persistent grid
+//   Hnsw::parallel_search          src/hnsw.rs:1612-1635   -> one wavefront per query, persistent grid; batches of
+//                                                             >= 256 queries are searched longest-first
+//                                                             (hnsw_estimate_kernel + order_desc_kernel)
 //   Hnsw::search_filter(None)      src/hnsw.rs:1487-1580   -> descent prologue + result epilogue
-//   Hnsw::search_layer             src/hnsw.rs:922-1064    -> expansion loop (visited set in LDS,
-//                                                             ef-bounded result/candidate set in VGPRs)
-//   Distance<f32>::eval            anndists 0.1            -> dist_row<METRIC>: one LANE per neighbour,
-//                                                             summed left-to-right exactly like the
+//   Hnsw::search_layer             src/hnsw.rs:922-1064    -> expansion loop (visited set in LDS, ef-bounded
+//                                                             result/candidate set in VGPRs; literal BinaryHeaps
+//                                                             for the queries that meet an exact f32 tie)
+//   Distance<f32>::eval            anndists 0.1            -> batch_dist<METRIC>: rows read by groups of lanes, each
+//                                                             distance summed left to right exactly like the
 //                                                             crate's scalar build (bit-identical)
 //
-// Arithmetic contract: every distance is accumulated in the reference's order (sequential over
-// the vector index, no FMA contraction), so ids AND f32 distances equal the CPU oracle bit for
-// bit on tie-free inputs.  Build with -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt.
+// Arithmetic contract: every distance is accumulated in the reference's order (sequential over the vector index, no
+// FMA contraction), so ids AND f32 distances equal the CPU oracle bit for bit.  Build with -ffp-contract=off
+// -fhip-fp32-correctly-rounded-divide-sqrt.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
