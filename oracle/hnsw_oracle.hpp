@@ -96,6 +96,36 @@ inline float dist_eval(DistKind k, const float* a, const float* b, size_t d) {
     }
     return NAN;
 }
+// The crate's `simdeez_f` feature (the "SIMD CPU path" of the reference's benchmarks) sums 8 f32 lanes
+// vertically and adds them horizontally at the end, then the scalar tail.  Restated with GCC vector extensions
+// (AVX2 when the host has it).  The sums differ from the scalar build in the last bits, so this variant is
+// used ONLY to time a SIMD CPU baseline (bench.py); every parity check runs the scalar functions above.
+typedef float v8f_t __attribute__((vector_size(32), aligned(4)));
+__attribute__((target_clones("avx2,fma", "default"))) inline float dist_simd8(DistKind k, const float* a, const float* b, size_t d) {
+    v8f_t acc = {0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc, acc2 = acc;
+    size_t i = 0;
+    for (; i + 8 <= d; i += 8) {
+        v8f_t x, y;
+        std::memcpy(&x, a + i, 32);
+        std::memcpy(&y, b + i, 32);
+        if (k == DIST_L2) { const v8f_t t = x - y; acc = acc + t * t; }
+        else if (k == DIST_L1) { const v8f_t t = x - y; acc = acc + (t < 0 ? -t : t); }
+        else { acc = acc + x * y; if (k == DIST_COSINE) { acc1 = acc1 + x * x; acc2 = acc2 + y * y; } }
+    }
+    float s = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < 8; ++j) { s += acc[j]; s1 += acc1[j]; s2 += acc2[j]; }
+    for (; i < d; ++i) {
+        if (k == DIST_L2) { const float t = a[i] - b[i]; s += t * t; }
+        else if (k == DIST_L1) s += std::fabs(a[i] - b[i]);
+        else { s += a[i] * b[i]; if (k == DIST_COSINE) { s1 += a[i] * a[i]; s2 += b[i] * b[i]; } }
+    }
+    switch (k) {
+        case DIST_L2: return std::sqrt(s);
+        case DIST_L1: return s;
+        case DIST_DOT: return std::max(1.f - s, 0.f);
+        default: return s1 > 0.f && s2 > 0.f ? std::max(1.f - s / std::sqrt(s1 * s2), 0.f) : 0.f;
+    }
+}
 // anndists::dist::distances::l2_normalize: divide by sqrt(sum x^2) (f32).
 inline void l2_normalize(float* v, size_t d) {
     float s = 0.f;
@@ -337,8 +367,10 @@ public:
     }
     uint8_t get_max_level_observed() const { return entry_point ? entry_point->p_id.layer : 0; }
 
+    bool simd_order = false;  // timing-only variant: the crate's SIMD summation order (dist_simd8)
     float eval(const float* a, const float* b, Counters* c) const {
         if (c) c->n_dist++;
+        if (simd_order) return dist_simd8(dist, a, b, data_dimension);
         return dist_eval(dist, a, b, data_dimension);
     }
 

@@ -101,6 +101,13 @@ int orc_parallel_search(void* hv, const float* queries, size_t nq, size_t d, siz
     ORC_CATCH(-1)
 }
 
+// timing-only switch: distances in the crate's SIMD summation order (see dist_simd8); never used by a parity check
+int orc_set_simd_order(void* hv, int on) {
+    ORC_TRY
+    static_cast<Hnsw*>(hv)->simd_order = on != 0;
+    return 0;
+    ORC_CATCH(-1)
+}
 // AnnT::file_dump (src/api.rs:70-93) without the unique-name logic: overwrites.
 int orc_file_dump(void* hv, const char* dir, const char* basename) {
     ORC_TRY

@@ -162,6 +162,10 @@ class OracleHnsw:
         res.counters = dict(n_dist=int(counters[0]), n_expand=int(counters[1]), n_ids_read=int(counters[2]))
         return res
 
+    def set_simd_order(self, on):
+        """Timing-only: distances summed in the crate's SIMD (8-lane) order; results differ in the last bits."""
+        lib().orc_set_simd_order(C.c_void_p(self.h), int(bool(on)))
+
     def file_dump(self, directory, basename):
         if lib().orc_file_dump(self.h, str(directory).encode(), basename.encode()) != 1:
             raise RuntimeError(_err())
