@@ -217,6 +217,23 @@ public:
         out = std::move(item);
         return true;
     }
+    void clear() { data.clear(); }
+    // BinaryHeap::retain (std, >= 1.70, recalled): Vec::retain keeps the survivors in order, remembering the index of
+    // the first element removed; the heap property is then restored for the tail only (rebuild_tail).
+    template <class F>
+    void retain(F keep) {
+        size_t rebuild_from = data.size(), i = 0, w = 0;
+        for (size_t r = 0; r < data.size(); ++r, ++i) {
+            if (keep(data[r])) {
+                if (w != r) data[w] = std::move(data[r]);
+                ++w;
+            } else if (i < rebuild_from) {
+                rebuild_from = i;
+            }
+        }
+        data.resize(w);
+        rebuild_tail(rebuild_from);
+    }
     std::vector<PWO> into_sorted_vec() {
         size_t end = data.size();
         while (end > 1) {
@@ -259,6 +276,26 @@ private:
             pos = child;
         }
         data[pos] = std::move(elt);
+    }
+    // rebuild_tail(start): elements [0, start) still form a heap.  Either heapify everything (rebuild) or sift the
+    // tail elements up one by one, by std's cost estimate.
+    void rebuild_tail(size_t start) {
+        if (start >= data.size()) return;
+        const size_t len = data.size(), tail_len = len - start;
+        auto log2_fast = [](size_t x) { size_t l = 0; while (x >>= 1) ++l; return l; };
+        bool better_to_rebuild;
+        if (start < tail_len) better_to_rebuild = true;
+        else if (len <= 2048) better_to_rebuild = 2 * len < tail_len * log2_fast(start);
+        else better_to_rebuild = 2 * len < tail_len * 11;
+        if (better_to_rebuild) {
+            size_t n = len / 2;        // rebuild(): sift_down every internal node, last first
+            while (n > 0) {
+                n -= 1;
+                sift_down_range(n, len);
+            }
+        } else {
+            for (size_t i = start; i < len; ++i) sift_up(0, i);
+        }
     }
     void sift_down_to_bottom(size_t pos) {
         size_t end = data.size();
@@ -374,9 +411,13 @@ public:
         return dist_eval(dist, a, b, data_dimension);
     }
 
-    // ---- search_layer, unfiltered branch (src/hnsw.rs:922-1064) --------------------------
+    // FilterT for Vec<usize> (src/filter.rs:11-15): binary search in a sorted vector of allowed origin ids
+    using Filter = std::vector<size_t>;
+    static bool hnsw_filter(const Filter& f, size_t id) { return std::binary_search(f.begin(), f.end(), id); }
+
+    // ---- search_layer (src/hnsw.rs:922-1064); filter == nullptr is the unfiltered branch --
     RustBinaryHeap search_layer(const float* point, std::shared_ptr<Point> entry, size_t ef,
-                                uint8_t layer, Counters* cnt) const {
+                                uint8_t layer, Counters* cnt, const Filter* filter = nullptr) const {
         RustBinaryHeap return_points;                                      // :940
         if (points_by_layer[layer].empty()) return return_points;          // :942-946
         if (entry->p_id.rank < 0) return return_points;                    // :947-950
@@ -392,7 +433,11 @@ public:
             const PWO& f = *return_points.peek();                          // :973
             if (!(f->dist_to_ref >= 0.f)) throw std::runtime_error("assert f.dist >= 0");
             if (!(c->dist_to_ref <= 0.f)) throw std::runtime_error("assert c.dist <= 0");
-            if (-(c->dist_to_ref) > f->dist_to_ref) return return_points;  // :981-993 (filter None)
+            if (-(c->dist_to_ref) > f->dist_to_ref) {                      // :981
+                if (!filter) return return_points;                         // :992-993
+                if (return_points.len() >= ef)                             // :994-1000: drop what the filter refuses,
+                    return_points.retain([&](const PWO& p) { return hnsw_filter(*filter, p->point_ref->origin_id); });
+            }                                                              // ... and carry on (no return with a filter)
             const auto& neighbours_c_l = c->point_ref->neighbours[layer];  // :1006
             if (cnt) { cnt->n_expand++; cnt->n_ids_read += neighbours_c_l.size(); }
             for (const PWO& e : neighbours_c_l) {                          // :1013
@@ -406,7 +451,15 @@ public:
                     if (e_dist_to_p < f_dist_to_p || return_points.len() < ef) {   // :1028
                         auto e_prime = std::make_shared<PointWithOrder>(e->point_ref, e_dist_to_p);
                         candidate_points.push(std::make_shared<PointWithOrder>(e->point_ref, -e_dist_to_p));
-                        return_points.push(e_prime);                       // :1038
+                        if (!filter) {
+                            return_points.push(e_prime);                   // :1038
+                        } else if (hnsw_filter(*filter, e_prime->point_ref->origin_id)) {  // :1040-1049
+                            if (return_points.len() == 1) {
+                                const size_t only_id = (*return_points.peek())->point_ref->origin_id;
+                                if (!hnsw_filter(*filter, only_id)) return_points.clear();
+                            }
+                            return_points.push(e_prime);
+                        }
                         if (return_points.len() > ef) {                    // :1051-1053
                             PWO dropped;
                             return_points.pop(dropped);
@@ -418,8 +471,9 @@ public:
         return return_points;                                              // :1063
     }
 
-    // ---- search_filter with filter = None (src/hnsw.rs:1487-1580) ------------------------
-    std::vector<Neighbour> search(const float* data, size_t knbn, size_t ef_arg, Counters* cnt = nullptr) const {
+    // ---- search_filter (src/hnsw.rs:1487-1580); filter == nullptr is Hnsw::search ---------
+    std::vector<Neighbour> search(const float* data, size_t knbn, size_t ef_arg, Counters* cnt = nullptr,
+                                  const Filter* filter = nullptr) const {
         if (!entry_point) return {};                                       // :1498-1503
         float dist_to_entry = eval(data, entry_point->v.data(), cnt);      // :1506
         std::shared_ptr<Point> pivot = entry_point;
@@ -441,14 +495,16 @@ public:
         size_t ef = std::max(ef_arg, knbn);                                // :1531
         uint8_t l = 0;                                                     // :1534-1540
         while (get_layer_nb_point(l) == 0) l++;
-        RustBinaryHeap heap = search_layer(data, pivot, ef, l, cnt);       // :1542
+        RustBinaryHeap heap = search_layer(data, pivot, ef, l, cnt, filter);  // :1542
         std::vector<PWO> neighbours = heap.into_sorted_vec();              // :1544
         size_t last = std::min(std::min(knbn, ef), neighbours.size());     // :1547
         std::vector<Neighbour> out;
         out.reserve(last);
-        for (size_t i = 0; i < last; ++i)                                  // :1567-1578
+        for (size_t i = 0; i < last; ++i) {                                // :1549-1578
+            if (filter && !hnsw_filter(*filter, neighbours[i]->point_ref->origin_id)) continue;  // filter_map :1551-1563
             out.push_back(Neighbour{neighbours[i]->point_ref->origin_id, neighbours[i]->dist_to_ref,
                                     neighbours[i]->point_ref->p_id});
+        }
         return out;
     }
 

@@ -101,6 +101,25 @@ int orc_parallel_search(void* hv, const float* queries, size_t nq, size_t d, siz
     ORC_CATCH(-1)
 }
 
+// Hnsw::search_filter(data, knbn, ef, Some(&Vec<usize>)) (src/hnsw.rs:1487): `allowed` = sorted origin ids
+int orc_search_filter(void* hv, const float* q, size_t d, size_t k, size_t ef, const uint64_t* allowed, size_t n_allowed,
+                      uint64_t* out_ids, float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_count) {
+    ORC_TRY
+    Hnsw* h = static_cast<Hnsw*>(hv);
+    if (h->data_dimension && d != h->data_dimension) throw std::runtime_error("search: dimension mismatch");
+    Hnsw::Filter f(allowed, allowed + n_allowed);
+    if (!std::is_sorted(f.begin(), f.end())) throw std::runtime_error("search_filter: the id vector must be sorted");
+    auto r = h->search(q, k, ef, nullptr, &f);
+    for (size_t j = 0; j < r.size(); ++j) {
+        out_ids[j] = r[j].d_id;
+        out_dists[j] = r[j].distance;
+        if (out_layer) out_layer[j] = r[j].p_id.layer;
+        if (out_rank) out_rank[j] = r[j].p_id.rank;
+    }
+    *out_count = (uint32_t)r.size();
+    return 0;
+    ORC_CATCH(-1)
+}
 // timing-only switch: distances in the crate's SIMD summation order (see dist_simd8); never used by a parity check
 int orc_set_simd_order(void* hv, int on) {
     ORC_TRY
@@ -157,6 +176,26 @@ int orc_heap_exercise(const float* vals, const int32_t* tags, size_t n, int mode
         }
         return (int)npop;
     }
+    auto v = hp.into_sorted_vec();
+    for (size_t i = 0; i < v.size(); ++i) {
+        out_vals[i] = v[i]->dist_to_ref;
+        out_tags[i] = v[i]->point_ref->p_id.rank;
+    }
+    return (int)v.size();
+    ORC_CATCH(-1)
+}
+
+// BinaryHeap::retain driver for unit tests: push all values, retain the entries whose keep[i] != 0 (i = push index),
+// then into_sorted_vec.
+int orc_heap_retain(const float* vals, const int32_t* tags, const uint8_t* keep, size_t n, float* out_vals, int32_t* out_tags) {
+    ORC_TRY
+    RustBinaryHeap hp;
+    float dummy[1] = {0.f};
+    for (size_t i = 0; i < n; ++i) {
+        auto p = std::make_shared<Point>(dummy, 1, i, PointId{0, tags[i]});   // origin_id = push index
+        hp.push(std::make_shared<PointWithOrder>(p, vals[i]));
+    }
+    hp.retain([&](const PWO& e) { return keep[e->point_ref->origin_id] != 0; });
     auto v = hp.into_sorted_vec();
     for (size_t i = 0; i < v.size(); ++i) {
         out_vals[i] = v[i]->dist_to_ref;

@@ -63,6 +63,9 @@ def lib():
         L.orc_levels.argtypes = [C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_heap_exercise.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                         C.c_void_p]
+        L.orc_search_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_heap_retain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_heap_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -162,6 +165,22 @@ class OracleHnsw:
         res.counters = dict(n_dist=int(counters[0]), n_expand=int(counters[1]), n_ids_read=int(counters[2]))
         return res
 
+    def search_filter(self, q, k, ef, allowed_ids):
+        """Hnsw::search_filter with a sorted Vec<usize> filter (src/hnsw.rs:1487, src/filter.rs:11-15)."""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        allowed = np.ascontiguousarray(allowed_ids, dtype=np.uint64)
+        ids = np.zeros(k, np.uint64)
+        dists = np.zeros(k, np.float32)
+        layers = np.zeros(k, np.uint8)
+        ranks = np.zeros(k, np.int32)
+        cnt = C.c_uint32(0)
+        rc = lib().orc_search_filter(C.c_void_p(self.h), _p(q), len(q), k, ef, _p(allowed), len(allowed), _p(ids), _p(dists),
+                                     _p(layers), _p(ranks), C.byref(cnt))
+        if rc != 0:
+            raise RuntimeError(_err())
+        c = cnt.value
+        return ids[:c], dists[:c], layers[:c], ranks[:c]
+
     def set_simd_order(self, on):
         """Timing-only: distances summed in the crate's SIMD (8-lane) order; results differ in the last bits."""
         lib().orc_set_simd_order(C.c_void_p(self.h), int(bool(on)))
@@ -216,3 +235,16 @@ def heap_script(vals, tags, is_pop):
     if r < 0:
         raise RuntimeError(_err())
     return ov[:npop.value], ot[:npop.value], sv[:r], st[:r]
+
+
+def heap_retain(vals, tags, keep):
+    """push all, BinaryHeap::retain(keep[push index]), into_sorted_vec -> (vals, tags)."""
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    tags = np.ascontiguousarray(tags, dtype=np.int32)
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    n = len(vals)
+    ov, ot = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    r = lib().orc_heap_retain(_p(vals), _p(tags), _p(keep), n, _p(ov), _p(ot))
+    if r < 0:
+        raise RuntimeError(_err())
+    return ov[:r], ot[:r]
