@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds a kernel A/B variant next to the product library: the four metric translation units recompiled with extra
+# -D flags, linked with the already-built host objects.
+#   tools/mkvariant.sh NAME "-DHNSW_LB_WAVES=4 ..."   ->  hnswlib-rs_amd/lib_NAME.so
+# Run it on the GPU box side by side with the default build in ONE gpurun call (the graph differs per box):
+#   HNSW_MI355X_LIB=$PWD/hnswlib-rs_amd/lib_NAME.so python bench.py --no-cpu-baseline --no-recall | python tools/bench_line.py
+# Variant libraries are git-ignored (*.so) but travel with gpurun: delete them when done.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT/hnswlib-rs_amd/csrc"
+make -j8 > /dev/null
+OBJ=/tmp/hnsw_variant_$1
+mkdir -p $OBJ
+for m in l2 cosine dot l1; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread --offload-arch=gfx950 \
+      -fhip-fp32-correctly-rounded-divide-sqrt $2 -c search_kernels_$m.hip -o $OBJ/$m.o &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 -o ../lib_$1.so hnswio.o builder.o capi.o search_device.o \
+    $OBJ/l2.o $OBJ/cosine.o $OBJ/dot.o $OBJ/l1.o -Wl,-rpath,/opt/rocm/lib
+ls -la ../lib_$1.so
