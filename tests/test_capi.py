@@ -104,3 +104,20 @@ def test_search_without_a_gpu_fails_loudly(native, tmp_path):
 def test_empty_index_search_returns_empty(native):
     h = native.Hnsw(8, 10, 16, 20, "DistL2")
     assert h.parallel_search(uniform(3, 4, 1), 2, 5) == [[], [], []]  # src/hnsw.rs:1498-1503
+
+
+def test_plain_c_caller_of_the_reference_style_symbols(native, tmp_path):
+    """include/hnsw_mi355x.h is C99; a C program builds, dumps, reloads and describes an index through the crate's
+    own FFI symbol names (src/libext.rs) without touching the GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "c", "caller.c")
+    exe = str(tmp_path / "caller")
+    libdir = os.path.join(root, "hnswlib-rs_amd")
+    subprocess.run(["gcc", "-std=c11", "-D_DEFAULT_SOURCE", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, "-o", exe,
+                    "-L", libdir, "-lhnsw_mi355x", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    work = tmp_path / "work"
+    work.mkdir()
+    r = subprocess.run([exe, str(work)], capture_output=True, text=True)
+    assert r.returncode == 0, f"exit {r.returncode}: {r.stdout} {r.stderr}"
+    assert (work / "c_caller.hnsw.graph").exists() and (work / "c_caller.hnsw.data").exists()
