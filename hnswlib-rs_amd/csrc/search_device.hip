@@ -373,6 +373,21 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             }
             a.cand_scratch = static_cast<hent_t*>(d_cand_);
             a.cand_cap = cap;
+#if defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME
+            {   // experiment: heap-operation log of the first attempt (same size as the candidate scratch)
+                static void* d_oplog = nullptr;
+                static uint64_t oplog_bytes = 0;
+                if (need > oplog_bytes) {
+                    if (d_oplog) (void)hipFree(d_oplog);
+                    d_oplog = nullptr;
+                    oplog_bytes = 0;
+                    HIP_TRY(hipMalloc(&d_oplog, need));
+                    oplog_bytes = need;
+                }
+                a.oplog = static_cast<hent_t*>(d_oplog);
+                a.oplog_cap = cap;
+            }
+#endif
             // most queries of the previous batch met a tie (integer-valued data does that): skip the first attempt
             a.exact_first = (adapt_exact_ef_ == ef && adapt_exact_first_) ? 1u : 0u;
             if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;

@@ -43,6 +43,10 @@ struct SearchArgs {
     uint32_t cand_cap;
     uint32_t cand_lds;      // strict ties: entries of candidate_points kept in LDS (behind the visited table)
     uint32_t exact_first;   // strict ties: skip the sorted-array attempt, answer every query with the literal heaps
+#if defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME
+    hent_t* oplog;          // experiment: [gridDim.x][oplog_cap] per-workgroup log of the first attempt's heap operations
+    uint32_t oplog_cap;
+#endif
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
