@@ -33,6 +33,18 @@ namespace hnswgpu {
 
 namespace {
 
+#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
+// DistCosine's third sum for every point, once: f32 squares widened to f64, summed left to right (padding adds 0.0)
+__global__ void row_sq_norms_kernel(const float* __restrict__ vec, double* __restrict__ out, uint32_t n, uint32_t row_stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = vec + (size_t)i * row_stride;
+    double s2 = 0.;
+    for (uint32_t c = 0; c < row_stride; ++c) s2 = s2 + (double)(r[c] * r[c]);
+    out[i] = s2;
+}
+#endif
+
 // queries [nq][d] -> [nq][row_stride] zero padded
 __global__ void pad_queries_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t nq, uint32_t d,
                                    uint32_t row_stride) {
@@ -81,7 +93,7 @@ DeviceIndex::~DeviceIndex() { release(); }
 
 void DeviceIndex::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_qpad_, &d_ctrl_, &d_retry_[0], &d_retry_[1],
+    void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_nrm2_, &d_qpad_, &d_ctrl_, &d_retry_[0], &d_retry_[1],
                      &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_cand_, &d_predist_, &d_order_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
     for (void** p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -169,6 +181,15 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     HIP_TRY(hipMalloc(&d_origin_, n * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(d_origin_, x.origin_id.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
     bytes_ += n * sizeof(uint64_t);
+#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
+    if (x.dist == DIST_COSINE) {
+        HIP_TRY(hipMalloc(&d_nrm2_, n * sizeof(double)));
+        hipLaunchKernelGGL(row_sq_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, static_cast<const float*>(d_vec_),
+                           static_cast<double*>(d_nrm2_), (uint32_t)n, v.row_stride);
+        HIP_TRY(hipDeviceSynchronize());
+        bytes_ += n * sizeof(double);
+    }
+#endif
     HIP_TRY(hipMalloc(&d_ctrl_, 64));
     hipEvent_t e0, e1, e2;
     HIP_TRY(hipEventCreate(&e0));
@@ -317,6 +338,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             a.tbits = tb;
         }
         a.tile_bytes = tile_bytes;
+#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
+        a.nrm2 = static_cast<const double*>(d_nrm2_);
+#endif
         a.idbits = idbits;
         const KernelSet& ks = kernel_set(dist_);
         const bool strict_kernel = strict_ties_ && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");

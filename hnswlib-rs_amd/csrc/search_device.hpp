@@ -70,6 +70,7 @@ private:
     void* d_up_ptr_ = nullptr;
     void* d_up_ids_ = nullptr;
     void* d_origin_ = nullptr;
+    void* d_nrm2_ = nullptr;      // HNSW_COSINE_GROUPS builds: per-point squared norms (f64)
     // per-call workspace (grown on demand)
     void* d_qpad_ = nullptr;      uint64_t qpad_cap_ = 0;     // padded queries
     void* d_ctrl_ = nullptr;                                   // work counter, overflow counter

@@ -43,6 +43,9 @@ struct SearchArgs {
     uint32_t cand_cap;
     uint32_t cand_lds;      // strict ties: entries of candidate_points kept in LDS (behind the visited table)
     uint32_t exact_first;   // strict ties: skip the sorted-array attempt, answer every query with the literal heaps
+#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
+    const double* nrm2;     // experiment: [n] squared norm of every point, f64 left-to-right sum of f32 squares (= DistCosine's third sum)
+#endif
 #if defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME
     hent_t* oplog;          // experiment: [gridDim.x][oplog_cap] per-workgroup log of the first attempt's heap operations
     uint32_t oplog_cap;
@@ -81,7 +84,11 @@ struct KernelSet {
 };
 // LDS in front of the id buffer: cosine transposes row tiles through it, the other metrics keep the query there
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
+#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
+    return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE ? 16u : 0u);  // + the query's squared norm (f64)
+#else
     return metric == DIST_COSINE ? TILE_BYTES : ((row_stride * 4u + 15u) & ~15u);
+#endif
 }
 const KernelSet& kernels_l2();
 const KernelSet& kernels_cosine();
