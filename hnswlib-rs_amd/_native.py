@@ -21,17 +21,30 @@ DIST_NAME = {v: k for k, v in DIST.items()}
 def build_native(force=False, verbose=False):
     """Compile every HIP/C++ source for gfx950 into libhnsw_mi355x.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
-            if f.endswith((".cpp", ".hip", ".hpp")) or f == "Makefile"]
+            if f.endswith((".cpp", ".hip", ".hpp", ".inc")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "hnsw_mi355x.h"))
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+
+    def fresh():
+        return (os.path.exists(LIB_PATH)
+                and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs))
+
+    if not force and fresh():
         return LIB_PATH
-    r = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
-    if verbose or r.returncode != 0:
-        print(r.stdout)
-        print(r.stderr)
-    if r.returncode != 0:
-        raise RuntimeError("building libhnsw_mi355x.so failed")
+    # one process per GPU may get here at the same time (bench.py --gpus N): build under a lock, the others then
+    # find the library up to date
+    import fcntl
+    with open(os.path.join(CSRC_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not fresh():
+                r = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+                if verbose or r.returncode != 0:
+                    print(r.stdout)
+                    print(r.stderr)
+                if r.returncode != 0:
+                    raise RuntimeError("building libhnsw_mi355x.so failed")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
