@@ -1,0 +1,230 @@
+"""Design check (CPU) for the HNSW_STRICT_RESUME experiment of the search kernel (search_kernels.inc): the first attempt
+keeps return_points / candidate_points as ONE sorted array and logs its heap operations; at the first insertion that
+meets an equal distance the two literal BinaryHeaps are rebuilt from the log and the search carries on with them --
+the rest of the interrupted batch first.  The claim: the answer equals the reference's (the oracle's) literal search
+also on data where nearly every query meets ties.  This file restates that control flow in Python (same batch
+structure, same hand-over point) on graphs read back through the product's host API, and compares with the oracle."""
+import numpy as np
+import pytest
+
+EXPAND = None
+
+
+# ---- literal std::collections::BinaryHeap on (key, payload) pairs, compared by key only (checked against the oracle below)
+def _sift_up(d, pos):
+    e = d[pos]
+    while pos > 0:
+        par = (pos - 1) // 2
+        if e[0] <= d[par][0]:
+            break
+        d[pos] = d[par]
+        pos = par
+    d[pos] = e
+
+
+def heap_push(d, x):
+    d.append(x)
+    _sift_up(d, len(d) - 1)
+
+
+def heap_pop(d):
+    item = d.pop()
+    if d:
+        item, d[0] = d[0], item
+        end, pos, e, child = len(d), 0, d[0], 1
+        while end >= 2 and child <= end - 2:
+            if d[child][0] <= d[child + 1][0]:
+                child += 1
+            d[pos] = d[child]
+            pos = child
+            child = 2 * pos + 1
+        if child == end - 1:
+            d[pos] = d[child]
+            pos = child
+        d[pos] = e
+        _sift_up(d, pos)
+    return item
+
+
+def heap_into_sorted(d):
+    d = list(d)
+    end = len(d)
+    while end > 1:
+        end -= 1
+        d[0], d[end] = d[end], d[0]
+        pos, e, child = 0, d[0], 1
+        while end >= 2 and child <= end - 2:
+            if d[child][0] <= d[child + 1][0]:
+                child += 1
+            if e[0] >= d[child][0]:
+                break
+            d[pos] = d[child]
+            pos = child
+            child = 2 * pos + 1
+        else:
+            if child == end - 1 and e[0] < d[child][0]:
+                d[pos] = d[child]
+                pos = child
+        d[pos] = e
+    return d
+
+
+def test_python_heap_matches_the_oracle(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        n = int(rng.integers(5, 400))
+        vals = rng.integers(0, 5, n).astype(np.float32)
+        pops = (rng.random(n) < 0.35).astype(np.uint8)
+        pv, pt, sv, st = oracle.heap_script(vals, np.arange(n), pops)
+        d, got = [], []
+        for i in range(n):
+            if pops[i]:
+                if d:
+                    got.append(heap_pop(d)[1])
+            else:
+                heap_push(d, (float(vals[i]), i))
+        assert got == pt.tolist()
+        assert [e[1] for e in heap_into_sorted(d)] == st.tolist()
+
+
+class Graph:
+    """Layer-0 lists and vectors of an index, through the product's host getters."""
+
+    def __init__(self, h, X, dist, oracle):
+        self.h, self.X, self.dist, self.oracle = h, X, dist, oracle
+        self.cache = {}
+
+    def nbrs(self, p, layer):          # p = (origin, layer, rank)
+        key = (p, layer)
+        if key not in self.cache:
+            ids, layers, ranks, _ = self.h.get_neighbours(p[1], p[2], layer)
+            self.cache[key] = [(int(i), int(l), int(r)) for i, l, r in zip(ids, layers, ranks)]
+        return self.cache[key]
+
+    def d(self, q, p):
+        return self.oracle.dist_eval(self.dist, q, self.X[p[0]])
+
+
+def descent(g, q):
+    origin, (layer, rank) = g.h.get_entry_point()
+    pivot = (origin, layer, rank)
+    dcur = g.d(q, pivot)
+    for l in range(layer, 0, -1):
+        best, best_p = dcur, None
+        for nb in g.nbrs(pivot, l):
+            dd = g.d(q, nb)
+            if dd < best:
+                best, best_p = dd, nb
+        if best_p is not None:
+            dcur, pivot = best, best_p
+    return pivot, dcur
+
+
+def search_with_resume(g, q, k, ef, batch=64):
+    """Returns (answer ids, resumed?)."""
+    pivot, dcur = descent(g, q)
+    R = [[dcur, pivot, False]]          # sorted ascending, arrival order among equals; flag = expanded
+    visited = {pivot}
+    log = []
+    state = None                        # set at the hand-over: (candidate heap, result heap)
+
+    def accept_exact(C, RR, cands):
+        for xd, p in cands:
+            if xd < RR[0][0] or len(RR) < ef:
+                heap_push(C, (-xd, p))
+                heap_push(RR, (xd, p))
+                if len(RR) > ef:
+                    heap_pop(RR)
+
+    while state is None:
+        cj = next((j for j, e in enumerate(R) if not e[2]), None)
+        if cj is None:
+            break
+        R[cj][2] = True
+        c = R[cj][1]
+        log.append(EXPAND)
+        lst = g.nbrs(c, 0)
+        for b0 in range(0, len(lst), batch):
+            fresh = [p for p in lst[b0:b0 + batch] if p not in visited]
+            visited.update(fresh)
+            de = [(g.d(q, p), p) for p in fresh]
+            worst = R[-1][0]
+            cand = [x for x in de if len(R) < ef or x[0] < worst]     # the ballot at the start of the batch
+            for i, (xd, p) in enumerate(cand):
+                if xd < worst or len(R) < ef:
+                    log.append((xd, p))
+                    tie = any(e[0] == xd for e in R)
+                    pos = sum(1 for e in R if e[0] <= xd)
+                    R.insert(pos, [xd, p, False])
+                    if len(R) > ef:
+                        R.pop()
+                    if tie:
+                        # hand over: rebuild both heaps from the log ...
+                        C, RR = [], []
+                        heap_push(C, (-dcur, pivot))
+                        heap_push(RR, (dcur, pivot))
+                        for op in log:
+                            if op is EXPAND:
+                                heap_pop(C)
+                            else:
+                                heap_push(C, (-op[0], op[1]))
+                                heap_push(RR, op)
+                                if len(RR) > ef:
+                                    heap_pop(RR)
+                        # ... offer the rest of this batch, then the remaining batches of this expansion
+                        accept_exact(C, RR, cand[i + 1:])
+                        for b1 in range(b0 + batch, len(lst), batch):
+                            fresh = [p2 for p2 in lst[b1:b1 + batch] if p2 not in visited]
+                            visited.update(fresh)
+                            de2 = [(g.d(q, p2), p2) for p2 in fresh]
+                            w = RR[0][0]
+                            accept_exact(C, RR, [x for x in de2 if len(RR) < ef or x[0] < w])
+                        state = (C, RR)
+                        break
+                    worst = R[-1][0]
+            if state is not None:
+                break
+    if state is None:
+        return [e[1][0] for e in R[:k]], False
+    C, RR = state
+    while C:
+        ce = heap_pop(C)
+        if -ce[0] > RR[0][0]:
+            break
+        for b0 in range(0, len(g.nbrs(ce[1], 0)), batch):
+            fresh = [p for p in g.nbrs(ce[1], 0)[b0:b0 + batch] if p not in visited]
+            visited.update(fresh)
+            de = [(g.d(q, p), p) for p in fresh]
+            w = RR[0][0]
+            accept_exact(C, RR, [x for x in de if len(RR) < ef or x[0] < w])
+    out = heap_into_sorted(RR)
+    return [e[1][0] for e in out[:min(k, ef)]], True
+
+
+@pytest.mark.parametrize("kind,dist,ef,m", [("grid", "DistL2", 16, 8), ("duplicates", "DistL2", 24, 8), ("grid", "DistL1", 40, 40),
+                                             ("uniform", "DistL2", 32, 12)])
+def test_resume_from_log_equals_the_literal_search(native, oracle, tmp_path, kind, dist, ef, m):
+    rng = np.random.default_rng(91)
+    n, d = 1200, 6
+    if kind == "duplicates":
+        base = rng.random((n // 2, d), dtype=np.float32)
+        X = np.concatenate([base, base])[rng.permutation(n)]
+    elif kind == "grid":
+        X = rng.integers(0, 4, (n, d)).astype(np.float32)
+    else:
+        X = rng.random((n, d), dtype=np.float32)
+    X = np.ascontiguousarray(X)
+    o = oracle.OracleHnsw(m, n, 16, 60, dist)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "r")
+    h = native.HnswIo(tmp_path, "r").load_hnsw(dist)
+    g = Graph(h, X, dist, oracle)
+    resumed = 0
+    for qi in range(40):
+        q = rng.integers(0, 4, d).astype(np.float32) if kind == "grid" else rng.random(d, dtype=np.float32)
+        ids, was = search_with_resume(g, q, 10, ef, batch=16)   # M=40 lists span several batches of 16
+        resumed += was
+        ref_ids, _, _, _ = o.search(q, 10, ef)
+        assert ids == ref_ids.tolist(), f"query {qi} ({'resumed' if was else 'tie free'})"
+    if kind != "uniform":
+        assert resumed > 10    # the tie-heavy data sets do exercise the hand-over
