@@ -397,7 +397,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             }
             a.cand_scratch = static_cast<hent_t*>(d_cand_);
             a.cand_cap = cap;
-#if defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME
+#if (defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME) || (defined(HNSW_EXACT_VALUE_R) && HNSW_EXACT_VALUE_R)
             {   // experiment: heap-operation log of the first attempt (same size as the candidate scratch)
                 static void* d_oplog = nullptr;
                 static uint64_t oplog_bytes = 0;

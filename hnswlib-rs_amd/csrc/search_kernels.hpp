@@ -46,7 +46,7 @@ struct SearchArgs {
 #if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
     const double* nrm2;     // experiment: [n] squared norm of every point, f64 left-to-right sum of f32 squares (= DistCosine's third sum)
 #endif
-#if defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME
+#if (defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME) || (defined(HNSW_EXACT_VALUE_R) && HNSW_EXACT_VALUE_R)
     hent_t* oplog;          // experiment: [gridDim.x][oplog_cap] per-workgroup log of the first attempt's heap operations
     uint32_t oplog_cap;
 #endif

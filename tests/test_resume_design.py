@@ -228,3 +228,76 @@ def test_resume_from_log_equals_the_literal_search(native, oracle, tmp_path, kin
         assert ids == ref_ids.tolist(), f"query {qi} ({'resumed' if was else 'tie free'})"
     if kind != "uniform":
         assert resumed > 10    # the tie-heavy data sets do exercise the hand-over
+
+
+def search_literal_c_value_r(g, q, k, ef):
+    """Second design check.  Only candidate_points needs its literal heap during the search: return_points influences
+    the trajectory through its largest VALUE and its length alone, so it can stay a value-sorted array, and its
+    literal heap is rebuilt from the log of its operations at the END -- and only if a choice between equal entries
+    can have reached the answer: an eviction between two equal farthest entries whose survivor is still in the top k,
+    or equal neighbours inside the answer (or across its end).  Returns (ids, replayed?)."""
+    pivot, dcur = descent(g, q)
+    C = []
+    heap_push(C, (-dcur, pivot))
+    R = [[dcur, pivot, False]]          # [distance, point, tainted]
+    rlog = [(dcur, pivot)]
+    visited = {pivot}
+    while C:
+        ce = heap_pop(C)
+        if -ce[0] > R[-1][0]:
+            break
+        for p in g.nbrs(ce[1], 0):
+            if p in visited:
+                continue
+            visited.add(p)
+            xd = g.d(q, p)
+            if xd < R[-1][0] or len(R) < ef:
+                heap_push(C, (-xd, p))
+                rlog.append((xd, p))
+                pos = sum(1 for e in R if e[0] <= xd)
+                R.insert(pos, [xd, p, False])
+                if len(R) > ef:
+                    if R[-1][0] == R[-2][0]:     # which of the equal farthest entries leaves depends on the heap layout
+                        R[-2][2] = True          # ... so whoever stays is tainted (all entries at that distance)
+                        for e in R:
+                            if e[0] == R[-1][0]:
+                                e[2] = True
+                    R.pop()
+    kk = min(k, ef, len(R))
+    need = any(e[2] for e in R[:kk]) or any(R[j][0] == R[j + 1][0] for j in range(kk) if j + 1 < len(R))
+    if not need:
+        return [e[1][0] for e in R[:kk]], False
+    RR = []
+    for op in rlog:
+        heap_push(RR, op)
+        if len(RR) > ef:
+            heap_pop(RR)
+    return [e[1][0] for e in heap_into_sorted(RR)[:kk]], True
+
+
+@pytest.mark.parametrize("kind,dist,ef,m", [("grid", "DistL2", 16, 8), ("duplicates", "DistL2", 24, 8), ("grid", "DistL1", 40, 40),
+                                             ("uniform", "DistL2", 32, 12), ("grid", "DistL2", 12, 6)])
+def test_value_sorted_result_set_with_literal_candidate_heap(native, oracle, tmp_path, kind, dist, ef, m):
+    rng = np.random.default_rng(17)
+    n, d = 1200, 6
+    if kind == "duplicates":
+        base = rng.random((n // 2, d), dtype=np.float32)
+        X = np.concatenate([base, base])[rng.permutation(n)]
+    elif kind == "grid":
+        X = rng.integers(0, 4, (n, d)).astype(np.float32)
+    else:
+        X = rng.random((n, d), dtype=np.float32)
+    X = np.ascontiguousarray(X)
+    o = oracle.OracleHnsw(m, n, 16, 60, dist)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "v")
+    h = native.HnswIo(tmp_path, "v").load_hnsw(dist)
+    g = Graph(h, X, dist, oracle)
+    replayed = 0
+    for qi in range(60):
+        q = rng.integers(0, 4, d).astype(np.float32) if kind == "grid" else rng.random(d, dtype=np.float32)
+        ids, was = search_literal_c_value_r(g, q, 10, ef)
+        replayed += was
+        ref_ids, _, _, _ = o.search(q, 10, ef)
+        assert ids == ref_ids.tolist(), f"query {qi} ({'R replayed' if was else 'R by value'})"
+    print(f"{kind} {dist} ef={ef}: return_points replayed for {replayed} of 60 queries")
