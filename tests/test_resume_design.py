@@ -301,3 +301,125 @@ def test_value_sorted_result_set_with_literal_candidate_heap(native, oracle, tmp
         ref_ids, _, _, _ = o.search(q, 10, ef)
         assert ids == ref_ids.tolist(), f"query {qi} ({'R replayed' if was else 'R by value'})"
     print(f"{kind} {dist} ef={ef}: return_points replayed for {replayed} of 60 queries")
+
+
+def search_end_state(g, q, k, ef, batch=16):
+    """Both experiments together (the intended end state): first attempt with a log; at the first equal pair only
+    candidate_points is rebuilt as a literal heap, return_points simply stays the value-sorted array it already is
+    (taint tracking starts there: before the first equal pair no eviction can have been ambiguous), and the log keeps
+    growing so that return_points can be rebuilt literally at the end if an equal-entry choice reached the answer."""
+    pivot, dcur = descent(g, q)
+    R = [[dcur, pivot, False, False]]     # distance, point, expanded (first attempt only), tainted
+    visited = {pivot}
+    log = []
+    C = None
+
+    def offer(cands):                     # literal candidate heap + value-sorted result set
+        for xd, p in cands:
+            if xd < R[-1][0] or len(R) < ef:
+                heap_push(C, (-xd, p))
+                log.append((xd, p))
+                pos = sum(1 for e in R if e[0] <= xd)
+                R.insert(pos, [xd, p, False, False])
+                if len(R) > ef:
+                    if R[-1][0] == R[-2][0]:
+                        for e in R:
+                            if e[0] == R[-1][0]:
+                                e[3] = True
+                    R.pop()
+
+    while C is None:
+        cj = next((j for j, e in enumerate(R) if not e[2]), None)
+        if cj is None:
+            break
+        R[cj][2] = True
+        c = R[cj][1]
+        log.append(EXPAND)
+        lst = g.nbrs(c, 0)
+        for b0 in range(0, len(lst), batch):
+            fresh = [p for p in lst[b0:b0 + batch] if p not in visited]
+            visited.update(fresh)
+            de = [(g.d(q, p), p) for p in fresh]
+            worst = R[-1][0]
+            cand = [x for x in de if len(R) < ef or x[0] < worst]
+            for i, (xd, p) in enumerate(cand):
+                if xd < worst or len(R) < ef:
+                    log.append((xd, p))
+                    tie = any(e[0] == xd for e in R)
+                    pos = sum(1 for e in R if e[0] <= xd)
+                    R.insert(pos, [xd, p, False, False])
+                    if len(R) > ef:
+                        R.pop()       # (no equal pair so far: the evicted entry was the unique farthest)
+                    if tie:
+                        C = []
+                        heap_push(C, (-dcur, pivot))
+                        for op in log:
+                            if op is EXPAND:
+                                heap_pop(C)
+                            else:
+                                heap_push(C, (-op[0], op[1]))
+                        offer(cand[i + 1:])
+                        for b1 in range(b0 + batch, len(lst), batch):
+                            fresh = [p2 for p2 in lst[b1:b1 + batch] if p2 not in visited]
+                            visited.update(fresh)
+                            w = R[-1][0]
+                            offer([x for x in [(g.d(q, p2), p2) for p2 in fresh] if len(R) < ef or x[0] < w])
+                        break
+                    worst = R[-1][0]
+            if C is not None:
+                break
+    if C is not None:
+        while C:
+            ce = heap_pop(C)
+            if -ce[0] > R[-1][0]:
+                break
+            lst = g.nbrs(ce[1], 0)
+            for b0 in range(0, len(lst), batch):
+                fresh = [p for p in lst[b0:b0 + batch] if p not in visited]
+                visited.update(fresh)
+                w = R[-1][0]
+                offer([x for x in [(g.d(q, p), p) for p in fresh] if len(R) < ef or x[0] < w])
+    kk = min(k, ef, len(R))
+    need = any(e[3] for e in R[:kk]) or any(R[j][0] == R[j + 1][0] for j in range(kk) if j + 1 < len(R))
+    if not need:
+        return [e[1][0] for e in R[:kk]], C is not None, False
+    RR = []
+    heap_push(RR, (dcur, pivot))
+    for op in log:
+        if op is not EXPAND:
+            heap_push(RR, op)
+            if len(RR) > ef:
+                heap_pop(RR)
+    return [e[1][0] for e in heap_into_sorted(RR)[:kk]], C is not None, True
+
+
+@pytest.mark.parametrize("kind,dist,ef,m", [("grid", "DistL2", 16, 8), ("duplicates", "DistL2", 24, 8), ("grid", "DistL1", 40, 40),
+                                             ("uniform", "DistL2", 32, 12), ("sparse-ties", "DistL2", 24, 10)])
+def test_end_state_design_equals_the_literal_search(native, oracle, tmp_path, kind, dist, ef, m):
+    rng = np.random.default_rng(29)
+    n, d = 1200, 6
+    if kind == "duplicates":
+        base = rng.random((n // 2, d), dtype=np.float32)
+        X = np.concatenate([base, base])[rng.permutation(n)]
+    elif kind == "grid":
+        X = rng.integers(0, 4, (n, d)).astype(np.float32)
+    elif kind == "sparse-ties":          # mostly distinct distances, a few exact duplicates: like natural data
+        X = rng.random((n, d), dtype=np.float32)
+        X[rng.choice(n, 60, replace=False)] = X[rng.choice(n, 60, replace=False)]
+    else:
+        X = rng.random((n, d), dtype=np.float32)
+    X = np.ascontiguousarray(X)
+    o = oracle.OracleHnsw(m, n, 16, 60, dist)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "e")
+    h = native.HnswIo(tmp_path, "e").load_hnsw(dist)
+    g = Graph(h, X, dist, oracle)
+    handed = rebuilt = 0
+    for qi in range(50):
+        q = rng.integers(0, 4, d).astype(np.float32) if kind == "grid" else rng.random(d, dtype=np.float32)
+        ids, was, rep = search_end_state(g, q, 10, ef)
+        handed += was
+        rebuilt += rep
+        ref_ids, _, _, _ = o.search(q, 10, ef)
+        assert ids == ref_ids.tolist(), f"query {qi} (handed over: {was}, result heap rebuilt: {rep})"
+    print(f"{kind} {dist} ef={ef}: {handed} of 50 queries handed over to the literal candidate heap, {rebuilt} rebuilt return_points")
