@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,25 @@ __global__ void pad_queries_kernel(const float* __restrict__ src, float* __restr
         }                                                                                      \
     } while (0)
 
+// A search call ends with one read-back of the counters.  The kernels of this path run for milliseconds, and a blocking
+// wait costs ~0.1 ms of wake-up latency per call: poll first, block only when the work is long.
+hipError_t wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipStreamSynchronize(s);
+    }
+}
+hipError_t wait_event(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(ev);
+    }
+}
+
 uint32_t ceil_log2(uint64_t x) {
     uint32_t b = 0;
     while ((1ull << b) < x) ++b;
@@ -97,6 +117,7 @@ void DeviceIndex::release() {
                      &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_cand_, &d_predist_, &d_order_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
     for (void** p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (h_ctrl_) { (void)hipHostFree(h_ctrl_); h_ctrl_ = nullptr; }
     if (ev_start_) { (void)hipEventDestroy((hipEvent_t)ev_start_); ev_start_ = nullptr; }
     if (ev_stop_) { (void)hipEventDestroy((hipEvent_t)ev_stop_); ev_stop_ = nullptr; }
     if (ev_mid_) { (void)hipEventDestroy((hipEvent_t)ev_mid_); ev_mid_ = nullptr; }
@@ -191,6 +212,7 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     }
 #endif
     HIP_TRY(hipMalloc(&d_ctrl_, 64));
+    HIP_TRY(hipHostMalloc(&h_ctrl_, 64, hipHostMallocDefault));
     hipEvent_t e0, e1, e2;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -422,9 +444,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (launches == 0) HIP_TRY(hipEventRecord((hipEvent_t)ev_ke_, stream));
         last_args = a;
         ++launches;
-        uint32_t ctrl[6] = {0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(ctrl, d_ctrl_, 24, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(h_ctrl_);  // pinned: a true asynchronous copy
+        HIP_TRY(hipMemcpyAsync(h_ctrl_, d_ctrl_, 24, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(wait_stream(stream));
         n_ties = ctrl[4];        // flagged for the replay kernel (cumulative over relaunches)
         n_converted = ctrl[5];   // needed the literal heaps inside the launch
         if (launches == 1 && strict_kernel && nq >= 256) {
@@ -495,13 +517,13 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
         HIP_TRY(kernel_set(dist_).launch_exact(ns, grid, lds, stream, v_, a, x));
         ++launches;
-        uint32_t ctrl2[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(ctrl2, d_ctrl_, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        volatile uint32_t* ctrl2 = static_cast<volatile uint32_t*>(h_ctrl_);
+        HIP_TRY(hipMemcpyAsync(h_ctrl_, d_ctrl_, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(wait_stream(stream));
         if (ctrl2[1] != 0) { err = "internal error: candidate heap overflow in the exact replay"; return ERR_DEVICE; }
     }
     HIP_TRY(hipEventRecord((hipEvent_t)ev_stop_, stream));
-    HIP_TRY(hipEventSynchronize((hipEvent_t)ev_stop_));
+    HIP_TRY(wait_event((hipEvent_t)ev_stop_));
     float ms = 0.f, ms_main = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev_start_, (hipEvent_t)ev_stop_));
     HIP_TRY(hipEventElapsedTime(&ms_main, (hipEvent_t)ev_ks_, (hipEvent_t)ev_ke_));  // first launch of the search kernel alone

@@ -74,6 +74,7 @@ private:
     // per-call workspace (grown on demand)
     void* d_qpad_ = nullptr;      uint64_t qpad_cap_ = 0;     // padded queries
     void* d_ctrl_ = nullptr;                                   // work counter, overflow counter
+    void* h_ctrl_ = nullptr;                                   // pinned host copy of the counters (read back once per launch)
     void* d_retry_[2] = {nullptr, nullptr}; uint64_t retry_cap_ = 0;
     void* d_stats_ = nullptr;     uint64_t stats_cap_ = 0;
     void* d_bitmap_ = nullptr;    uint64_t bitmap_cap_ = 0;
