@@ -430,7 +430,9 @@ public:
         while (!candidate_points.is_empty()) {                             // :969
             PWO c;
             candidate_points.pop(c);                                       // :971
-            const PWO& f = *return_points.peek();                          // :973
+            if (!return_points.peek())                                     // :973 `peek().unwrap()`: with a filter that emptied
+                throw std::runtime_error("search_layer: return_points is empty (the reference panics here)");
+            const PWO& f = *return_points.peek();
             if (!(f->dist_to_ref >= 0.f)) throw std::runtime_error("assert f.dist >= 0");
             if (!(c->dist_to_ref <= 0.f)) throw std::runtime_error("assert c.dist <= 0");
             if (-(c->dist_to_ref) > f->dist_to_ref) {                      // :981
