@@ -94,7 +94,9 @@ def ground_truth(torch, Xd, Qd, k, dist):
 
 def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cnt, cpu_seconds):
     """Times the oracle (CPU restatement of the reference, test infrastructure) on the same graph and queries and
-    compares the device answers with it.  Returns (cpu_baseline, parity) for the bench line."""
+    compares the device answers with it.  Returns (cpu_baseline, parity) for the bench line.
+    Protocol: wall time of the whole batched call, 1 warm-up + median of 5, on a sample of the batch sized
+    for about `cpu_seconds` of CPU work in total."""
     import oracle_lib
     nq_local = Q.shape[0]
     cores = os.cpu_count() or 1
@@ -104,56 +106,73 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     probe = min(nq_local, 256)
     r = orc.parallel_search(Q[:probe], k, ef, cores)
     rate = probe / max(r.elapsed_s, 1e-6)
-    sample = int(min(nq_local, max(probe, rate * cpu_seconds)))
+    # ~24 timed calls below (2 thread counts x 2 arithmetic orders x 6 runs): size the sample for the budget
+    sample = int(min(nq_local, max(probe, rate * cpu_seconds / 24.0)))
+
+    def median_of_5(fn):
+        fn()  # warm-up
+        return float(np.median([sample / fn().elapsed_s for _ in range(5)]))
+
     # Rayon's default is one thread per logical core; on a many-core box the Arc refcounts of hub nodes
     # bounce between sockets, so a quarter of the cores is timed as well and the better rate is reported
-    trials = {}
-    for nt in sorted({cores, max(1, cores // 4)}, reverse=True):
-        rr = orc.parallel_search(Q[:sample], k, ef, nt)
-        trials[nt] = sample / rr.elapsed_s
-        if nt == cores:
-            r = rr
+    threads = sorted({cores, max(1, cores // 4)}, reverse=True)
+    trials = {nt: median_of_5(lambda nt=nt: orc.parallel_search(Q[:sample], k, ef, nt)) for nt in threads}
+    r = orc.parallel_search(Q, k, ef, cores)  # scalar (reference-order) answers of the WHOLE batch for the parity check
     best_threads = max(trials, key=trials.get)
     cpu_qps = trials[best_threads]
     # the reference's published numbers use its SIMD feature build: the same search with the distances summed in
     # the crate's 8-lane order (timing only; last-bit differences, so parity below uses the scalar answers)
     orc.set_simd_order(True)
-    simd_trials = {}
-    for nt in sorted(trials, reverse=True):
-        best = 0.0
-        for _ in range(2):
-            best = max(best, sample / orc.parallel_search(Q[:sample], k, ef, nt).elapsed_s)
-        simd_trials[nt] = best
+    simd_trials = {nt: median_of_5(lambda nt=nt: orc.parallel_search(Q[:sample], k, ef, nt)) for nt in threads}
     orc.set_simd_order(False)
     simd_threads = max(simd_trials, key=simd_trials.get)
     arithmetic = "scalar (bit-exact order)"
     if simd_trials[simd_threads] > cpu_qps:
         cpu_qps, best_threads = simd_trials[simd_threads], simd_threads
         arithmetic = "simd-order (8 f32 lanes, the crate's simdeez_f build)"
-    # Parity at full size.  status 2 = the kernel met an exact f32 distance tie while inserting: the
-    # reference's answer then depends on its binary heaps' internal order (DESIGN.md "ties"), so those
-    # queries are reported separately.
-    gpu_ids = res_ids[:sample].astype(np.uint64)
-    gpu_bits = np.ascontiguousarray(res_dists[:sample], dtype=np.float32).view(np.uint32)
-    tie_flag = (st[:sample, 3] == 2) | (st[:sample, 3] == 3)
-    exact_used = st[:sample, 3] == 3
-    row_ids_ok = np.all(r.ids == gpu_ids, axis=1) & (r.counts == cnt[:sample].astype(np.uint32))
+    # for honesty: the same search freed of the reference's data model (flat arrays, epoch visited array, SIMD-order
+    # sums, prefetch: oracle/flat_baseline.hpp) -- what the host cores can do, NOT the reference's cost structure
+    flat = orc.flat_baseline()
+    flat_sample = int(min(nq_local, sample * 8))
+    flat_trials = {}
+    for nt in threads:
+        flat.parallel_search(Q[:flat_sample], k, ef, nt)
+        flat_trials[nt] = float(np.median([flat_sample / flat.parallel_search(Q[:flat_sample], k, ef, nt).elapsed_s for _ in range(5)]))
+    flat_threads = max(flat_trials, key=flat_trials.get)
+    fr = flat.parallel_search(Q[:sample], k, ef, cores)
+    flat_agree = float(np.mean(fr.ids == r.ids[:sample]))
+    del flat
+    # Parity at full size.  status 2 = the kernel met a decision that depends on the reference's heap order and did not
+    # resolve it (strict ties off), 3 = resolved with the literal heaps (DESIGN.md "ties").
+    gpu_ids = res_ids.astype(np.uint64)
+    gpu_bits = np.ascontiguousarray(res_dists, dtype=np.float32).view(np.uint32)
+    tie_flag = (st[:, 3] == 2) | (st[:, 3] == 3)
+    exact_used = st[:, 3] == 3
+    row_ids_ok = np.all(r.ids == gpu_ids, axis=1) & (r.counts == cnt.astype(np.uint32))
     row_bits_ok = np.all(r.dists.view(np.uint32) == gpu_bits, axis=1)
-    parity = {"queries_checked": int(sample),
+    parity = {"queries_checked": int(nq_local),
+              "all_ids_identical": bool(row_ids_ok.all()),
+              "all_f32_distance_bits_identical": bool(row_bits_ok.all()),
               "tie_free_queries": int((~tie_flag).sum()),
               "tie_free_ids_identical": bool(row_ids_ok[~tie_flag].all()),
               "tie_free_f32_distance_bits_identical": bool(row_bits_ok[~tie_flag].all()),
-              "queries_with_exact_distance_tie": int(tie_flag.sum()),
-              "tied_queries_resolved_with_literal_heaps": int(exact_used.sum()),
-              "tied_queries_ids_identical": int(row_ids_ok[tie_flag].sum()),
-              "tied_queries_distance_bits_identical": int(row_bits_ok[tie_flag].sum())}
+              "queries_that_met_equal_distances": int((st[:, 7] & 1).sum()),
+              "queries_whose_answer_depends_on_heap_order": int(tie_flag.sum()),
+              "resolved_with_literal_heaps": int(exact_used.sum()),
+              "heap_order_queries_ids_identical": int(row_ids_ok[tie_flag].sum()),
+              "heap_order_queries_distance_bits_identical": int(row_bits_ok[tie_flag].sum())}
     cpu_baseline = {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": best_threads, "kind": "port",
-                    "arithmetic": arithmetic,
+                    "arithmetic": arithmetic, "protocol": "1 warm-up + median of 5 batched calls",
                     "by_threads": {str(t): round(v, 1) for t, v in trials.items()},
                     "by_threads_simd_order": {str(t): round(v, 1) for t, v in simd_trials.items()},
-                    "sample": f"first {sample} of the same {nq_local} queries, same graph (reloaded from the same hnswio dump), "
-                              f"oracle parallel_search (Rayon-style worker threads; best of {sorted(trials)} threads on a {cores}-core host, "
-                              f"scalar and SIMD-order distances), {r.elapsed_s:.1f} s at {cores} threads (scalar)"}
+                    "flat_avx": {"value": round(flat_trials[flat_threads], 1), "cores": flat_threads,
+                                 "by_threads": {str(t): round(v, 1) for t, v in flat_trials.items()},
+                                 "ids_agreeing_with_the_port": round(flat_agree, 4),
+                                 "note": "same algorithm on flat arrays with SIMD-order sums and prefetch (oracle/flat_baseline.hpp): "
+                                         "an optimised CPU implementation, not the reference's data model"},
+                    "sample": f"first {sample} of the same {nq_local} queries (flat variant: {flat_sample}), same graph (reloaded from the "
+                              f"same hnswio dump), oracle parallel_search (Rayon-style worker threads; best of {threads} threads on a "
+                              f"{cores}-core host, scalar and SIMD-order distances)"}
     del orc
     return cpu_baseline, parity
 
@@ -176,7 +195,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (gloo only to exercise the multi-rank path on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (1-GPU box test of the N>1 path)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--batches", type=int, default=4, help="distinct query batches the steps rotate through (a step that "
+                    "re-searches the batch of the previous step finds its rows in the 256 MiB Infinity Cache)")
     args = ap.parse_args()
 
     import torch  # first: the C-ABI library then binds to the HIP runtime torch already loaded
@@ -247,12 +268,16 @@ def main():
         f"max_level={index.get_max_level_observed()}")
 
     # ---------------------------------------------------------------- queries (resident in HBM)
+    # NB distinct batches; step i searches batch i % NB, so that consecutive steps do not touch the same rows
     nq_total = nq_local * world
-    Q_all = synth(nq_total, d, 0x5EED0002, args.data)
+    NB = max(1, args.batches)
+    Q_all = synth(nq_total * NB, d, 0x5EED0002, args.data)
     if cfg["dist"] == "DistDot":
         Q_all /= np.linalg.norm(Q_all, axis=1, keepdims=True)
-    Q = Q_all[rank * nq_local:(rank + 1) * nq_local]
-    Qd = torch.from_numpy(np.ascontiguousarray(Q)).to(dev)
+    Qh = [np.ascontiguousarray(Q_all[b * nq_total + rank * nq_local: b * nq_total + (rank + 1) * nq_local]) for b in range(NB)]
+    Q = Qh[0]
+    Qds = [torch.from_numpy(q).to(dev) for q in Qh]
+    Qd = Qds[0]
     out_ids = torch.zeros((nq_local, k), dtype=torch.int64, device=dev)
     out_dists = torch.zeros((nq_local, k), dtype=torch.float32, device=dev)
     out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
@@ -267,8 +292,8 @@ def main():
     kernel_ms = []
     main_ms = []
 
-    def step():
-        rc = lib.hnswgpu_search_batch_device(index.handle, Qd.data_ptr(), nq_local, d, k, ef, out_ids.data_ptr(),
+    def step(i):
+        rc = lib.hnswgpu_search_batch_device(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, out_ids.data_ptr(),
                                              out_dists.data_ptr(), out_layer.data_ptr(), out_rank.data_ptr(),
                                              out_counts.data_ptr(), stats.data_ptr(), stream.cuda_stream)
         if rc != 0:
@@ -285,45 +310,44 @@ def main():
             dist_pg.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    kernel_ms.clear()
-    main_ms.clear()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist_pg.all_reduce(t, op=dist_pg.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-    qps = nq_total * args.steps / elapsed
-    stats_strict = stats.clone()
-
-    # for reference: the same steps with strict ties OFF (equal distances ordered by arrival, queries flagged)
-    fast_qps = None
-    if lib.hnswgpu_set_strict_ties(index.handle, 0) == 0:
-        step()
+    def timed(nsteps):
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(nsteps):
+            step(i)
         fence()
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist_pg.all_reduce(t, op=dist_pg.ReduceOp.MAX)
             el = float(t.item())
-        fast_qps = nq_total * args.steps / el
-        lib.hnswgpu_set_strict_ties(index.handle, 1)
-        step()   # leave the strict answers in the output buffers for the recall / parity checks below
+        return el
+
+    for i in range(args.warmup):
+        step(i)
+    kernel_ms.clear()
+    main_ms.clear()
+    elapsed = timed(args.steps)
+    ms_per_step = elapsed * 1e3 / args.steps
+    qps = nq_total * args.steps / elapsed
+    timed_main_ms = list(main_ms)
+    timed_kernel_ms = list(kernel_ms)
+
+    # untimed accounting: one more step per batch for its work counters (the algorithmic bytes of that batch)
+    batch_stats = []
+    for b in range(NB):
+        step(b)
         fence()
-        kernel_ms[:] = kernel_ms[:args.steps]
-        main_ms[:] = main_ms[:args.steps]
-    stats.copy_(stats_strict)
+        batch_stats.append(stats.cpu().numpy().astype(np.int64))
+
+    # for reference: the same steps with strict ties OFF (equal distances ordered by arrival, queries flagged)
+    fast_qps = None
+    if lib.hnswgpu_set_strict_ties(index.handle, 0) == 0:
+        step(0)
+        fast_qps = nq_total * args.steps / timed(args.steps)
+        lib.hnswgpu_set_strict_ties(index.handle, 1)
+    step(0)   # leave the strict answers of batch 0 in the output buffers for the recall / parity checks below
+    fence()
 
     # ---------------------------------------------------------------- recall vs exact brute force
     res_ids = out_ids.cpu().numpy()
@@ -354,34 +378,52 @@ def main():
     recall_id, recall_dist = recall[0] / recall[2], recall[1] / recall[2]
 
     # ---------------------------------------------------------------- roofline of the search kernel
-    st = stats.cpu().numpy().astype(np.int64)
+    st = stats.cpu().numpy().astype(np.int64)   # batch 0, strict
     if args.dump_stats and rank == 0:
         np.save(args.dump_stats, st)
-    n_dist, n_expand, n_ids = int(st[:, 0].sum()), int(st[:, 1].sum()), int(st[:, 2].sum())
-    # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded
-    alg_bytes = n_dist * d * 4 + n_ids * 4 + n_expand * 8 + nq_local * (d * 4 + k * 12)
-    # the dominant kernel is hnsw_search_kernel; the exact replay of tie-affected queries (strict ties)
-    # is a second, small kernel whose time is part of `value` but not of this kernel's roofline
-    k_ms = float(np.mean(main_ms)) if main_ms else float("nan")
-    all_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
+
+    def alg_bytes_of(sb):
+        # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded
+        return int(sb[:, 0].sum()) * d * 4 + int(sb[:, 2].sum()) * 4 + int(sb[:, 1].sum()) * 8 + nq_local * (d * 4 + k * 12)
+
+    batch_bytes = [alg_bytes_of(sb) for sb in batch_stats]
+    n_dist, n_expand, n_ids = (int(sum(sb[:, c].sum() for sb in batch_stats)) / NB for c in (0, 1, 2))
+    # the dominant kernel is hnsw_search_kernel (queries that need the literal heaps carry on inside it); achieved =
+    # algorithmic bytes of the batches the timed steps searched / the kernel time of those launches (HIP events)
+    k_ms = float(np.mean(timed_main_ms)) if timed_main_ms else float("nan")
+    all_ms = float(np.mean(timed_kernel_ms)) if timed_kernel_ms else float("nan")
+    alg_bytes = float(np.mean([batch_bytes[i % NB] for i in range(args.steps)]))
+    achieved = sum(batch_bytes[i % NB] for i in range(args.steps)) / (sum(timed_main_ms) * 1e-3) / 1e9
+    traffic_profile = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
-            if tj.get("workload") == cfg["label"] and tj.get("data") == args.data:
-                traffic = tj.get("hbm_bytes_per_launch")
+            ent = tj.get(args.config)
+            if ent and ent.get("data") == args.data:
+                traffic_profile = ent
         except Exception:
             pass
+    index_bytes = n * (((d + 31) // 32) * 128 + 4 * ((2 * cfg["M"] + 15) // 16) * 16 + 8)
+    all_st = np.concatenate(batch_stats)
     roofline = {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(k_ms, 4),
-                "all_kernels_ms": round(all_ms, 4), "tie_replayed_queries": int((st[:, 3] == 3).sum()),
-                "launches_per_step": index.last_kernel_ms()[1],
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # PMC counters cannot be collected inside this process: `traffic` stays null here; the rocprofv3 --pmc
+                # measurement of the same command is quoted from the committed profile, with its file name
+                "traffic": None, "traffic_from_profile": traffic_profile,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
+                "all_kernels_ms": round(all_ms, 4),
+                "queries_resolved_with_literal_heaps": int((st[:, 3] == 3).sum()),
+                "queries_that_met_equal_distances": int((st[:, 7] & 1).sum()),
+                "launches_per_step": index.last_kernel_ms()[1], "query_batches_rotated": NB,
+                "index_bytes_in_hbm": int(index_bytes),
+                "resident_in_infinity_cache": bool(index_bytes < 256 * 2 ** 20),
+                "note": ("the whole index fits the 256 MiB Infinity Cache: the fetches behind `achieved` are served by MALL/L2, "
+                         "the fraction is against the HBM peak only by convention" if index_bytes < 256 * 2 ** 20 else
+                         "working set (vectors + lists) exceeds the Infinity Cache; batches rotate so that steps do not re-read each other's rows"),
                 "per_query": {"n_dist": n_dist / nq_local, "n_expand": n_expand / nq_local,
                               "n_ids_read": n_ids / nq_local, "bytes": alg_bytes / nq_local,
-                              "n_dist_p50_p99_max": [int(np.percentile(st[:, 0], 50)), int(np.percentile(st[:, 0], 99)), int(st[:, 0].max())]}}
+                              "n_dist_p50_p99_max": [int(np.percentile(all_st[:, 0], 50)), int(np.percentile(all_st[:, 0], 99)), int(all_st[:, 0].max())]}}
 
     # ---------------------------------------------------------------- CPU baseline (oracle = checker)
     cpu_baseline = None
@@ -400,7 +442,7 @@ def main():
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
                        "queries_total": nq_total, "graph": "replicated per GPU", "exchange": "all_gather of answers (RCCL)" if world > 1 else "none"},
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
-            "strict_ties": {"on": True, "note": "queries that meet an exact f32 distance tie switch to a literal emulation of the reference's BinaryHeaps (DESIGN.md section 6)",
+            "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

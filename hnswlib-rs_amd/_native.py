@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libhnsw_mi355x.so")
 # tuning hook: load a differently-built variant of the same library (kernel A/B runs in one process tree)
 LIB_OVERRIDE = os.environ.get("HNSW_MI355X_LIB")
 
-OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY = range(8)
+OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY, ERR_REF_PANIC = range(9)
 DIST = {"DistL2": 0, "DistCosine": 1, "DistDot": 2, "DistL1": 3}
 DIST_NAME = {v: k for k, v in DIST.items()}
 
@@ -90,6 +90,7 @@ SYMBOLS = {
     "hnswgpu_load_description": (_I, [C.c_char_p, C.POINTER(Description)]),
     "hnswgpu_get_description": (_I, [_VP, C.POINTER(Description)]),
     "hnswgpu_build": (_I, [_VP, _U64, _U64, _VP, C.POINTER(BuildParams), C.POINTER(_VP)]),
+    "hnswgpu_insert": (_I, [_VP, _VP, _U64, _U64, _VP, _I]),
     "hnswgpu_nb_point": (_U64, [_VP]),
     "hnswgpu_dimension": (_U64, [_VP]),
     "hnswgpu_dist": (_I, [_VP]),
@@ -101,11 +102,16 @@ SYMBOLS = {
     "hnswgpu_device_count": (_I, []),
     "hnswgpu_search_batch": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
     "hnswgpu_search_batch_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hnswgpu_search_batch_filtered": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hnswgpu_search_batch_sharded": (_I, [_VP, _VP, _I, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
+    "hnswgpu_search_batch_filtered_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP,
+                                                  _VP, C.POINTER(C.c_uint32)]),
     "hnswgpu_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "hnswgpu_last_search_kernel_ms": (_I, [_VP, C.POINTER(C.c_double)]),
     "hnswgpu_set_strict_ties": (_I, [_VP, _I]),
     "hnswgpu_last_tie_count": (_I, [_VP, C.POINTER(C.c_uint32)]),
     "hnswgpu_eval_distances": (_I, [_I, _VP, _VP, _U64, _U64, _VP]),
+    "hnswgpu_eval_distance_matrix": (_I, [_I, _VP, _U64, _VP, _U64, _U64, C.c_uint32, _VP]),
     # reference-compatible symbols (src/libext.rs)
     "get_hnswio": (_VP, [_U64, C.c_char_p]),
     "load_hnswdump_f32_DistL1": (_VP, [_VP]),

@@ -42,10 +42,12 @@ def _p(a):
 
 
 class BatchResult:
-    """Flat form of Vec<Vec<Neighbour>>: row i holds counts[i] valid entries, ascending distance."""
+    """Flat form of Vec<Vec<Neighbour>>: row i holds counts[i] valid entries, ascending distance.
+    status (filtered search only): 1 where the reference panics on the query (src/hnsw.rs:973), else 0."""
 
-    def __init__(self, ids, dists, layers, ranks, counts):
+    def __init__(self, ids, dists, layers, ranks, counts, status=None):
         self.ids, self.dists, self.layers, self.ranks, self.counts = ids, dists, layers, ranks, counts
+        self.status = status
 
     def to_neighbours(self):
         out = []
@@ -97,16 +99,19 @@ class Hnsw:
 
     # ---- insertion (host construction; src/hnsw.rs:1069-1238) ---------------------------
     def parallel_insert(self, data, ids=None):
-        """data: (n, d) f32 matrix; ids: origin ids (default 0..n-1).  One call per index."""
+        """data: (n, d) f32 matrix; ids: origin ids (default: continue from the number of points).  The first call
+        builds the index; later calls -- also on an index reloaded from a dump -- keep inserting into it."""
         data = np.ascontiguousarray(data, dtype=np.float32)
         if data.ndim != 2:
             raise HnswError(N.ERR_ARG, "data must be a (n, d) matrix")
-        if self._h is not None:
-            raise HnswError(N.ERR_ARG, "this binding builds an index in one parallel_insert call")
         idp = None
         if ids is not None:
             ids = np.ascontiguousarray(ids, dtype=np.uint64)
             idp = _p(ids)
+        if self._h is not None:
+            nthreads = self._params.nthreads if hasattr(self, "_params") else 0
+            _check(self._lib.hnswgpu_insert(self._h, _p(data), data.shape[0], data.shape[1], idp, nthreads))
+            return
         h = C.c_void_p()
         _check(self._lib.hnswgpu_build(_p(data), data.shape[0], data.shape[1], idp, C.byref(self._params),
                                        C.byref(h)))
@@ -114,6 +119,11 @@ class Hnsw:
 
     def insert_serial(self, data, ids=None):
         """for (v, id) in data: hnsw.insert((v, id)) -- deterministic serial insertion."""
+        if not hasattr(self, "_params"):  # reloaded index
+            data = np.ascontiguousarray(data, dtype=np.float32)
+            idp = _p(np.ascontiguousarray(ids, dtype=np.uint64)) if ids is not None else None
+            _check(self._lib.hnswgpu_insert(self._h, _p(data), data.shape[0], data.shape[1], idp, 1))
+            return
         saved = self._params.nthreads
         self._params.nthreads = 1
         try:
@@ -179,6 +189,50 @@ class Hnsw:
         _check(self._lib.hnswgpu_search_batch(self._h, _p(datas), nq, d, knbn, ef, _p(ids), _p(dists), _p(layers),
                                               _p(ranks), _p(counts)))
         return BatchResult(ids, dists, layers, ranks, counts)
+
+    def parallel_search_sharded_flat(self, datas, knbn, ef, devices):
+        """Hnsw::parallel_search with the batch sharded over the GPUs `devices` of this process (graph replicated,
+        contiguous balanced blocks, answers gathered into one result; a device may be named more than once)."""
+        datas = np.ascontiguousarray(datas, dtype=np.float32)
+        nq, d = datas.shape
+        ids = np.zeros((nq, knbn), np.uint64)
+        dists = np.zeros((nq, knbn), np.float32)
+        layers = np.zeros((nq, knbn), np.uint8)
+        ranks = np.zeros((nq, knbn), np.int32)
+        counts = np.zeros(nq, np.uint32)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(self._lib.hnswgpu_search_batch_sharded(self._h, _p(dev), len(dev), _p(datas), nq, d, knbn, ef, _p(ids), _p(dists),
+                                                      _p(layers), _p(ranks), _p(counts)))
+        return BatchResult(ids, dists, layers, ranks, counts)
+
+    def parallel_search_filter_flat(self, datas, knbn, ef, allowed_ids):
+        """Hnsw::search_filter(data, knbn, ef, Some(&allowed_ids)) for every row of `datas` (src/hnsw.rs:1487-1580);
+        allowed_ids = the SORTED id vector of `impl FilterT for Vec<usize>` (src/filter.rs:11-15).  Rows on which the
+        reference panics come back with count 0 and status 1."""
+        datas = np.ascontiguousarray(datas, dtype=np.float32)
+        if datas.ndim != 2:
+            raise HnswError(N.ERR_ARG, "datas must be a (nq, d) matrix")
+        allowed = np.ascontiguousarray(allowed_ids, dtype=np.uint64)
+        nq, d = datas.shape
+        ids = np.zeros((nq, knbn), np.uint64)
+        dists = np.zeros((nq, knbn), np.float32)
+        layers = np.zeros((nq, knbn), np.uint8)
+        ranks = np.zeros((nq, knbn), np.int32)
+        counts = np.zeros(nq, np.uint32)
+        status = np.zeros(nq, np.uint8)
+        if self._h is None:
+            return BatchResult(ids, dists, layers, ranks, counts, status)
+        _check(self._lib.hnswgpu_search_batch_filtered(self._h, _p(datas), nq, d, knbn, ef, _p(allowed), len(allowed), _p(ids),
+                                                       _p(dists), _p(layers), _p(ranks), _p(counts), _p(status)))
+        return BatchResult(ids, dists, layers, ranks, counts, status)
+
+    def search_filter(self, data, knbn, ef, allowed_ids):
+        """Vec<Neighbour> of Hnsw::search_filter with a sorted id vector; raises where the reference panics."""
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(1, -1)
+        r = self.parallel_search_filter_flat(data, knbn, ef, allowed_ids)
+        if r.status[0]:
+            raise HnswError(N.ERR_REF_PANIC, "the reference panics on this query (return_points emptied by the filter, src/hnsw.rs:973)")
+        return r.to_neighbours()[0]
 
     def parallel_search(self, datas, knbn, ef):
         """Vec<Vec<Neighbour>> in input order (src/hnsw.rs:1612-1635)."""
@@ -253,8 +307,18 @@ def load_description(graph_file_path):
     return d
 
 
+def eval_distance_matrix(dist, queries, rows, batch):
+    """out[q][r] = Distance<f32>::eval(queries[q], rows[r]) on the device, by the search kernel's own distance routine with
+    the rows taken in batches of `batch` (1..64) -- the lane-group branches the search takes for that many neighbours."""
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    r = np.ascontiguousarray(rows, dtype=np.float32)
+    out = np.zeros((q.shape[0], r.shape[0]), np.float32)
+    _check(N.lib().hnswgpu_eval_distance_matrix(N.DIST[dist], _p(q), q.shape[0], _p(r), r.shape[0], q.shape[1], batch, _p(out)))
+    return out
+
+
 def eval_distances(dist, a, b):
-    """Distance<f32>::eval computed on the device, in the search kernel's arithmetic."""
+    """Distance<f32>::eval for the pairs (a[i], b[i]) on the device, by the search kernel's own distance routine."""
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)
     out = np.zeros(a.shape[0], np.float32)

@@ -170,6 +170,51 @@ GraphBuilder::GraphBuilder(const BuildParams& p) : p_(p) {
 }
 GraphBuilder::~GraphBuilder() = default;
 
+GraphBuilder::GraphBuilder(const FlatIndex& f, bool fast_arithmetic) {
+    p_.max_nb_connection = f.max_nb_connection;
+    p_.ef_construction = f.ef_construction;
+    p_.max_layer = f.nb_layer;
+    p_.dist = f.dist;
+    p_.extend_candidates = true;  // what load_hnsw sets on a reloaded index (src/hnswio.rs:510-511)
+    p_.keep_pruned = false;
+    p_.fast_arithmetic = fast_arithmetic;
+    max_layer_ = (unsigned)std::min<uint64_t>(NB_LAYER_MAX, std::max<uint64_t>(1, f.nb_layer));
+    // (the loader already applied the reference's reload rule to the dumped scale: see load_dump)
+    scale_ = f.level_scale;
+    p_.level_scale_factor = scale_ * std::log((double)std::max<uint64_t>(2, f.max_nb_connection));
+    for (auto& a : layer_inserted_) a.store(0);
+    layer_rank_next_.fill(0);
+    n_ = f.n;
+    d_ = f.dimension;
+    for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
+        layer_rank_next_[l] = f.layer_count(l);
+        layer_inserted_[l].store(f.layer_count(l));
+    }
+    for (uint64_t i = 0; i < n_; ++i) {
+        const uint32_t id = (uint32_t)i;
+        if ((id >> 16) >= chunks_.size()) {
+            chunks_.emplace_back(new Node[CHUNK]);
+            vecs_.emplace_back(new float[CHUNK * d_]);
+        }
+        Node& nd = node(id);
+        nd.level = (uint8_t)f.layer_of(id);
+        nd.rank = f.rank_of(id);
+        nd.origin = f.origin_id[i];
+        std::memcpy(vecs_[id >> 16].get() + (uint64_t)(id & (CHUNK - 1)) * d_, f.vectors.data() + i * d_, d_ * sizeof(float));
+        for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
+            const uint64_t b = f.nbr_ptr[i * NB_LAYER_MAX + l], e = f.nbr_ptr[i * NB_LAYER_MAX + l + 1];
+            if (e == b) continue;
+            std::vector<Edge>& lst = nd.list(l);
+            lst.resize(e - b);
+            for (uint64_t j = b; j < e; ++j) lst[j - b] = Edge{f.nbr_flat[j], f.nbr_dist[j]};
+        }
+    }
+    if (f.entry_flat != NO_POINT) {
+        entry_.store((int64_t)f.entry_flat);
+        entry_level_.store((int)f.layer_of(f.entry_flat));
+    }
+}
+
 float GraphBuilder::eval(const float* a, const float* b) const {
     if (!p_.fast_arithmetic) {
         switch (p_.dist) {

@@ -36,6 +36,11 @@ struct Edge {
 class GraphBuilder {
 public:
     explicit GraphBuilder(const BuildParams& p);
+    // Continue a reloaded index (HnswIo::load_hnsw gives a fully insertable Hnsw: load_point_indexation rebuilds the
+    // layer generator from the dumped level scale, src/hnswio.rs:720-737, :1119-1178).  Builder ids = the dump's flat
+    // ids; M, ef_construction, max_layer, the distance and the ABSOLUTE level scale come from the description; the
+    // level stream restarts (a reloaded reference index also starts a fresh generator).
+    GraphBuilder(const FlatIndex& loaded, bool fast_arithmetic);
     ~GraphBuilder();
     // insert n points (row-major n x d).  ids == nullptr: origin ids continue from nb_point().
     int insert_batch(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads, std::string& err);

@@ -2,9 +2,13 @@
 // name/layout-compatible replacements of the reference's own f32 FFI (src/libext.rs).
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hnsw_mi355x.h"
@@ -20,18 +24,34 @@ static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+// No C++ exception may cross the C ABI (the host may be Rust, Julia or C): every entry point runs inside this guard.
+#define CAPI_GUARD_BEGIN try {
+#define CAPI_GUARD_END(ret)                                                             \
+    } catch (const std::bad_alloc&) {                                                   \
+        fail(HNSWGPU_ERR_ARG, "out of memory");                                         \
+        return ret;                                                                     \
+    } catch (const std::exception& e) {                                                 \
+        fail(HNSWGPU_ERR_FORMAT, std::string("internal error: ") + e.what());           \
+        return ret;                                                                     \
+    } catch (...) {                                                                     \
+        fail(HNSWGPU_ERR_FORMAT, "internal error");                                     \
+        return ret;                                                                     \
+    }
 
 struct hnswgpu_index {
-    std::mutex mu;                          // one search / mutation at a time per handle
+    // Searches take this lock shared (they are `&self` in the reference: concurrent calls on one handle are legal);
+    // whatever changes the graph or the set of replicas (insert, upload, dump of a stale flat view) takes it exclusive.
+    std::shared_mutex mu;
     std::unique_ptr<FlatIndex> flat;        // dump-order view; rebuilt from `builder` when stale
-    std::unique_ptr<GraphBuilder> builder;  // present for indexes created by hnswgpu_build / init_hnsw_f32
+    std::unique_ptr<GraphBuilder> builder;  // construction state (created lazily for reloaded indexes)
     bool flat_stale = false;
-    std::unique_ptr<DeviceIndex> dev;
+    std::map<int, std::unique_ptr<DeviceIndex>> replicas;  // HBM replicas by HIP device ordinal
+    int primary = -1;                       // device of the single-GPU entry points
     bool dev_stale = true;
     int strict_ties = -1;  // -1: library default (env HNSWGPU_STRICT_TIES, else on)
     BuildParams params;
 
-    const FlatIndex* get_flat() {
+    const FlatIndex* get_flat() {  // exclusive lock held (or the view is known to be fresh)
         if (builder && (flat_stale || !flat)) {
             flat.reset(new FlatIndex());
             builder->finalize(*flat);
@@ -40,6 +60,11 @@ struct hnswgpu_index {
         }
         return flat.get();
     }
+    bool fresh() const { return flat && !flat_stale; }
+    DeviceIndex* replica(int device) const {
+        auto it = replicas.find(device);
+        return it == replicas.end() || !it->second->ready() ? nullptr : it->second.get();
+    }
 };
 
 static int default_device() {
@@ -47,22 +72,42 @@ static int default_device() {
     return e ? std::atoi(e) : 0;
 }
 
-// make sure the HBM replica reflects the host graph (lazy for the reference-style entry points)
+// make sure an HBM replica on `device` (< 0: the primary / default one) reflects the host graph.  Exclusive lock held.
 static int ensure_device(hnswgpu_index* idx, int device) {
     const FlatIndex* f = idx->get_flat();
     if (!f || f->n == 0) return fail(HNSWGPU_ERR_EMPTY, "index is empty");
-    if (idx->dev && idx->dev->ready() && !idx->dev_stale && (device < 0 || device == idx->dev->device())) return HNSWGPU_OK;
-    if (device < 0) device = idx->dev && idx->dev->ready() ? idx->dev->device() : default_device();
-    idx->dev.reset(new DeviceIndex());
-    std::string err;
-    int rc = idx->dev->upload(*f, device, err);
-    if (rc != OK) {
-        idx->dev.reset();
-        return fail(rc, err);
+    if (idx->dev_stale) {  // the graph changed: every replica is out of date
+        idx->replicas.clear();
+        idx->dev_stale = false;
     }
-    idx->dev_stale = false;
-    if (idx->strict_ties >= 0) idx->dev->set_strict_ties(idx->strict_ties != 0);
+    if (device < 0) device = idx->primary >= 0 ? idx->primary : default_device();
+    if (!idx->replica(device)) {
+        std::unique_ptr<DeviceIndex> dev(new DeviceIndex());
+        std::string err;
+        int rc = dev->upload(*f, device, err);
+        if (rc != OK) return fail(rc, err);
+        if (idx->strict_ties >= 0) dev->set_strict_ties(idx->strict_ties != 0);
+        idx->replicas[device] = std::move(dev);
+    }
+    if (idx->primary < 0 || !idx->replica(idx->primary)) idx->primary = device;
     return HNSWGPU_OK;
+}
+// the replica a search on the primary device uses; takes the exclusive lock only when something has to be (re)built
+static int primary_replica(hnswgpu_index* idx, std::shared_lock<std::shared_mutex>& sl, DeviceIndex** out) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (idx->fresh() && !idx->dev_stale && idx->primary >= 0 && idx->replica(idx->primary)) {
+            *out = idx->replica(idx->primary);
+            return HNSWGPU_OK;
+        }
+        sl.unlock();
+        {
+            std::unique_lock<std::shared_mutex> xl(idx->mu);
+            int rc = ensure_device(idx, -1);
+            if (rc != HNSWGPU_OK) { xl.unlock(); sl.lock(); return rc; }
+        }
+        sl.lock();
+    }
+    return fail(HNSWGPU_ERR_DEVICE, "index changed while a search was starting");
 }
 
 extern "C" {
@@ -70,6 +115,7 @@ extern "C" {
 const char* hnswgpu_last_error(void) { return g_last_error.c_str(); }
 
 int hnswgpu_load_dump(const char* dir, const char* basename, int dist, hnswgpu_index** out) {
+    CAPI_GUARD_BEGIN
     if (!dir || !basename || !out) return fail(HNSWGPU_ERR_ARG, "null argument");
     *out = nullptr;
     std::unique_ptr<hnswgpu_index> h(new hnswgpu_index());
@@ -79,18 +125,21 @@ int hnswgpu_load_dump(const char* dir, const char* basename, int dist, hnswgpu_i
     if (rc != OK) return fail(rc, err);
     *out = h.release();
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_FORMAT)
 }
 
 int hnswgpu_file_dump(const hnswgpu_index* cidx, const char* dir, const char* basename) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx || !dir || !basename) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     const FlatIndex* f = idx->get_flat();
     if (!f) return fail(HNSWGPU_ERR_EMPTY, "entry point not initialized");
     std::string err;
     int rc = write_dump(*f, dir, basename, err);
     if (rc != OK) return fail(rc, err);
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_IO)
 }
 
 void hnswgpu_free_index(hnswgpu_index* idx) { delete idx; }
@@ -111,6 +160,7 @@ static void fill_descr(hnswgpu_description* o, uint32_t ver, uint8_t mode, uint8
 }
 
 int hnswgpu_load_description(const char* graph_file_path, hnswgpu_description* out) {
+    CAPI_GUARD_BEGIN
     if (!graph_file_path || !out) return fail(HNSWGPU_ERR_ARG, "null argument");
     DumpDescription d;
     std::string err;
@@ -119,17 +169,20 @@ int hnswgpu_load_description(const char* graph_file_path, hnswgpu_description* o
     fill_descr(out, d.format_version, d.dumpmode, d.max_nb_connection, d.nb_layer, d.level_scale, d.ef, d.nb_point,
                d.dimension, d.distname, d.t_name);
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_FORMAT)
 }
 
 int hnswgpu_get_description(const hnswgpu_index* cidx, hnswgpu_description* out) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx || !out) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     const FlatIndex* f = idx->get_flat();
     if (!f) return fail(HNSWGPU_ERR_EMPTY, "index is empty");
     fill_descr(out, f->format_version, f->dumpmode, (uint8_t)f->max_nb_connection, f->nb_layer, f->level_scale,
                f->ef_construction, f->n, f->dimension, f->distname.empty() ? dist_type_name(f->dist) : f->distname, f->t_name);
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_FORMAT)
 }
 
 static BuildParams to_params(const hnswgpu_build_params* p) {
@@ -148,6 +201,7 @@ static BuildParams to_params(const hnswgpu_build_params* p) {
 
 int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, const hnswgpu_build_params* params,
                   hnswgpu_index** out) {
+    CAPI_GUARD_BEGIN
     if (!params || !out || (n && !data)) return fail(HNSWGPU_ERR_ARG, "null argument");
     *out = nullptr;
     if (params->dist < 0 || params->dist > 3) return fail(HNSWGPU_ERR_DISTANCE, "unknown distance");
@@ -162,59 +216,96 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
     h->flat_stale = true;
     *out = h.release();
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_ARG)
+}
+
+// Hnsw::insert / parallel_insert on ANY handle, reloaded ones included (HnswIo::load_hnsw returns a fully insertable
+// Hnsw).  Exclusive lock held by the caller.
+static int insert_points(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads) {
+    if (!idx->builder) {
+        if (!idx->flat) return fail(HNSWGPU_ERR_EMPTY, "handle holds no index");
+        idx->builder.reset(new GraphBuilder(*idx->flat, false));  // continue the reloaded graph (builder.hpp)
+        idx->params = idx->builder->params();
+    }
+    std::string err;
+    int rc = idx->builder->insert_batch(data, n, d, ids, nthreads, err);
+    if (rc != OK) return fail(rc, err);
+    idx->flat_stale = true;
+    idx->dev_stale = true;
+    return HNSWGPU_OK;
+}
+
+int hnswgpu_insert(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads) {
+    CAPI_GUARD_BEGIN
+    if (!idx || (n && !data)) return fail(HNSWGPU_ERR_ARG, "null argument");
+    std::unique_lock<std::shared_mutex> g(idx->mu);
+    return insert_points(idx, data, n, d, ids, nthreads);
+    CAPI_GUARD_END(HNSWGPU_ERR_ARG)
 }
 
 uint64_t hnswgpu_nb_point(const hnswgpu_index* cidx) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx) return 0;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::shared_lock<std::shared_mutex> g(idx->mu);
     if (idx->builder) return idx->builder->nb_point();
     return idx->flat ? idx->flat->n : 0;
+    CAPI_GUARD_END(0)
 }
 uint64_t hnswgpu_dimension(const hnswgpu_index* cidx) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx) return 0;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::shared_lock<std::shared_mutex> g(idx->mu);
     if (idx->builder) return idx->builder->dimension();
     return idx->flat ? idx->flat->dimension : 0;
+    CAPI_GUARD_END(0)
 }
 int hnswgpu_dist(const hnswgpu_index* cidx) {
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx) return -1;
+    std::shared_lock<std::shared_mutex> g(idx->mu);
     if (idx->builder) return idx->params.dist;
     return idx->flat ? idx->flat->dist : -1;
 }
 uint64_t hnswgpu_layer_nb_point(const hnswgpu_index* cidx, unsigned layer) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx || layer >= NB_LAYER_MAX) return 0;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     const FlatIndex* f = idx->get_flat();
     return f ? f->layer_count(layer) : 0;
+    CAPI_GUARD_END(0)
 }
 int hnswgpu_max_level_observed(const hnswgpu_index* cidx) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx) return 0;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     const FlatIndex* f = idx->get_flat();
     if (!f || f->entry_flat == NO_POINT) return 0;
     return (int)f->layer_of(f->entry_flat);
+    CAPI_GUARD_END(0)
 }
 int hnswgpu_entry_point(const hnswgpu_index* cidx, uint64_t* origin_id, uint8_t* layer, int32_t* rank) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     const FlatIndex* f = idx->get_flat();
     if (!f || f->entry_flat == NO_POINT) return fail(HNSWGPU_ERR_EMPTY, "index is empty");
     if (origin_id) *origin_id = f->origin_id[f->entry_flat];
     if (layer) *layer = (uint8_t)f->layer_of(f->entry_flat);
     if (rank) *rank = f->rank_of(f->entry_flat);
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_ARG)
 }
 int64_t hnswgpu_neighbours(const hnswgpu_index* cidx, unsigned layer, int32_t rank, unsigned l, uint64_t cap,
                            uint64_t* origin_ids, uint8_t* layers, int32_t* ranks, float* dists) {
+    CAPI_GUARD_BEGIN
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx || layer >= NB_LAYER_MAX || l >= NB_LAYER_MAX || rank < 0) { fail(HNSWGPU_ERR_ARG, "bad argument"); return -1; }
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     const FlatIndex* f = idx->get_flat();
     if (!f || (uint64_t)rank >= f->layer_count(layer)) { fail(HNSWGPU_ERR_ARG, "no such point"); return -1; }
     uint64_t flat = f->layer_offset[layer] + (uint64_t)rank;
@@ -227,83 +318,233 @@ int64_t hnswgpu_neighbours(const hnswgpu_index* cidx, unsigned layer, int32_t ra
         if (dists) dists[j - b] = f->nbr_dist[j];
     }
     return (int64_t)(e - b);
+    CAPI_GUARD_END(-1)
 }
 
 int hnswgpu_device_count(void) { return device_count(); }
 
 int hnswgpu_upload(hnswgpu_index* idx, int device) {
+    CAPI_GUARD_BEGIN
     if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
-    return ensure_device(idx, device);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
+    int rc = ensure_device(idx, device);
+    if (rc == HNSWGPU_OK && device >= 0) idx->primary = device;  // the last explicit upload names the primary device
+    return rc;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
+// shared implementation of the host-buffer searches on the primary replica
+static int search_host_common(const hnswgpu_index* cidx, const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
+                              const uint64_t* allowed, uint64_t n_allowed, bool filtered, uint64_t* out_ids, float* out_dists,
+                              uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts, uint8_t* out_status, uint32_t* panics) {
+    hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
+    if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
+    std::shared_lock<std::shared_mutex> sl(idx->mu);
+    const bool empty = idx->builder ? idx->builder->nb_point() == 0 : (!idx->flat || idx->flat->n == 0);
+    if (empty) {  // empty index => every answer is empty (src/hnsw.rs:1498-1503)
+        if (out_counts) std::memset(out_counts, 0, nq * sizeof(uint32_t));
+        if (out_status) std::memset(out_status, 0, nq);
+        if (panics) *panics = 0;
+        return HNSWGPU_OK;
+    }
+    DeviceIndex* dev = nullptr;
+    int rc = primary_replica(idx, sl, &dev);
+    if (rc != HNSWGPU_OK) return rc;
+    std::string err;
+    CallInfo info;
+    rc = dev->search_host(queries, nq, d, k, ef, out_ids, out_dists, out_layer, out_rank, out_counts, allowed, n_allowed, filtered,
+                          out_status, &info, err);
+    if (rc != OK) return fail(rc, err);
+    if (panics) *panics = info.panics;
+    return HNSWGPU_OK;
 }
 
 int hnswgpu_search_batch(const hnswgpu_index* cidx, const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
                          uint64_t* out_ids, float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts) {
+    CAPI_GUARD_BEGIN
+    return search_host_common(cidx, queries, nq, d, k, ef, nullptr, 0, false, out_ids, out_dists, out_layer, out_rank, out_counts,
+                              nullptr, nullptr);
+    CAPI_GUARD_END(HNSWGPU_ERR_ARG)
+}
+
+int hnswgpu_search_batch_filtered(const hnswgpu_index* cidx, const float* queries, uint64_t nq, uint64_t d, uint64_t k,
+                                  uint64_t ef, const uint64_t* allowed_ids, uint64_t n_allowed, uint64_t* out_ids,
+                                  float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
+                                  uint8_t* out_status) {
+    CAPI_GUARD_BEGIN
+    if (n_allowed && !allowed_ids) return fail(HNSWGPU_ERR_ARG, "null filter");
+    for (uint64_t i = 1; i < n_allowed; ++i)  // `impl FilterT for Vec<usize>` is a binary search: the vector must be sorted
+        if (allowed_ids[i - 1] > allowed_ids[i]) return fail(HNSWGPU_ERR_ARG, "the id vector of a filter must be sorted ascending");
+    uint32_t panics = 0;
+    int rc = search_host_common(cidx, queries, nq, d, k, ef, allowed_ids, n_allowed, true, out_ids, out_dists, out_layer, out_rank,
+                                out_counts, out_status, &panics);
+    if (rc != HNSWGPU_OK) return rc;
+    if (panics != 0 && !out_status)
+        return fail(HNSWGPU_ERR_REF_PANIC, "the reference panics on " + std::to_string(panics) +
+                    " of these queries (return_points.peek().unwrap() on a heap the filter emptied, src/hnsw.rs:973); "
+                    "pass out_status to learn which");
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_ARG)
+}
+
+// Hnsw::parallel_search with the batch sharded over several GPUs of this process: graph replicated (one replica per
+// distinct device, uploaded on first use), contiguous balanced blocks of queries, one host thread per shard, every shard
+// copies its answers straight into the caller's arrays -- the gather.  No collective: the shards are independent.
+int hnswgpu_search_batch_sharded(const hnswgpu_index* cidx, const int* devices, int n_shards, const float* queries, uint64_t nq,
+                                 uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dists, uint8_t* out_layer,
+                                 int32_t* out_rank, uint32_t* out_counts) {
+    CAPI_GUARD_BEGIN
+    hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
+    if (!idx || !devices || n_shards <= 0) return fail(HNSWGPU_ERR_ARG, "bad argument");
+    if (nq && (!queries || !out_ids || !out_dists || !out_counts)) return fail(HNSWGPU_ERR_ARG, "null buffer");
+    {   // replicas on every device named (exclusive: uploads change the handle)
+        std::unique_lock<std::shared_mutex> xl(idx->mu);
+        const bool empty = idx->builder ? idx->builder->nb_point() == 0 : (!idx->flat || idx->flat->n == 0);
+        if (empty) {
+            if (out_counts) std::memset(out_counts, 0, nq * sizeof(uint32_t));
+            return HNSWGPU_OK;
+        }
+        for (int s = 0; s < n_shards; ++s) {
+            int rc = ensure_device(idx, devices[s]);
+            if (rc != HNSWGPU_OK) return rc;
+        }
+    }
+    std::shared_lock<std::shared_mutex> sl(idx->mu);
+    if (!idx->fresh() || idx->dev_stale) return fail(HNSWGPU_ERR_DEVICE, "index changed while a search was starting");
+    std::vector<int> rcs((size_t)n_shards, OK);
+    std::vector<std::string> errs((size_t)n_shards);
+    std::vector<std::thread> th;
+    const uint64_t base = nq / (uint64_t)n_shards, rem = nq % (uint64_t)n_shards;  // shard s: base + (s < rem) queries
+    uint64_t start = 0;
+    for (int s = 0; s < n_shards; ++s) {
+        const uint64_t cnt = base + ((uint64_t)s < rem ? 1 : 0);
+        DeviceIndex* dev = idx->replica(devices[s]);
+        if (!dev) return fail(HNSWGPU_ERR_DEVICE, "replica missing");
+        const uint64_t s0 = start;
+        start += cnt;
+        if (cnt == 0) continue;
+        th.emplace_back([=, &rcs, &errs]() {
+            try {
+                rcs[(size_t)s] = dev->search_host(queries + s0 * d, cnt, d, k, ef, out_ids + s0 * k, out_dists + s0 * k,
+                                                  out_layer ? out_layer + s0 * k : nullptr, out_rank ? out_rank + s0 * k : nullptr,
+                                                  out_counts + s0, nullptr, 0, false, nullptr, nullptr, errs[(size_t)s]);
+            } catch (const std::exception& e) {
+                rcs[(size_t)s] = ERR_DEVICE;
+                errs[(size_t)s] = e.what();
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int s = 0; s < n_shards; ++s)
+        if (rcs[(size_t)s] != OK) return fail(rcs[(size_t)s], "shard " + std::to_string(s) + ": " + errs[(size_t)s]);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
+static int search_device_common(const hnswgpu_index* cidx, const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
+                                const uint64_t* d_allowed, uint64_t n_allowed, uint64_t* d_out_ids, float* d_out_dists,
+                                uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* d_stats, void* stream,
+                                uint32_t* panics) {
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
-    const FlatIndex* f = idx->get_flat();
-    if (!f || f->n == 0) {  // empty index => every answer is empty (src/hnsw.rs:1498-1503)
-        if (out_counts) std::memset(out_counts, 0, nq * sizeof(uint32_t));
-        return HNSWGPU_OK;
-    }
-    int rc = ensure_device(idx, -1);
-    if (rc != HNSWGPU_OK) return rc;
+    std::shared_lock<std::shared_mutex> sl(idx->mu);
+    DeviceIndex* dev = idx->primary >= 0 ? idx->replica(idx->primary) : nullptr;
+    if (!dev || idx->dev_stale || idx->flat_stale)
+        return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device: call hnswgpu_upload first");
     std::string err;
-    rc = idx->dev->search_host(queries, nq, d, k, ef, out_ids, out_dists, out_layer, out_rank, out_counts, err);
+    CallInfo info;
+    int rc = dev->search_device(d_queries, nq, d, k, ef, d_out_ids, d_out_dists, d_out_layer, d_out_rank, d_out_counts, d_stats,
+                                stream, d_allowed, n_allowed, &info, err);
     if (rc != OK) return fail(rc, err);
+    if (panics) *panics = info.panics;
     return HNSWGPU_OK;
 }
 
 int hnswgpu_search_batch_device(const hnswgpu_index* cidx, const float* d_queries, uint64_t nq, uint64_t d, uint64_t k,
                                 uint64_t ef, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
                                 int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* d_stats, void* stream) {
-    hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
-    if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
-    if (!idx->dev || !idx->dev->ready() || idx->dev_stale || idx->flat_stale)
-        return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device: call hnswgpu_upload first");
-    std::string err;
-    int rc = idx->dev->search_device(d_queries, nq, d, k, ef, d_out_ids, d_out_dists, d_out_layer, d_out_rank, d_out_counts,
-                                     d_stats, stream, err);
-    if (rc != OK) return fail(rc, err);
-    return HNSWGPU_OK;
+    CAPI_GUARD_BEGIN
+    return search_device_common(cidx, d_queries, nq, d, k, ef, nullptr, 0, d_out_ids, d_out_dists, d_out_layer, d_out_rank,
+                                d_out_counts, d_stats, stream, nullptr);
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
 }
 
+int hnswgpu_search_batch_filtered_device(const hnswgpu_index* cidx, const float* d_queries, uint64_t nq, uint64_t d, uint64_t k,
+                                         uint64_t ef, const uint64_t* d_allowed_ids, uint64_t n_allowed, uint64_t* d_out_ids,
+                                         float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
+                                         uint32_t* d_stats, void* stream, uint32_t* n_panics) {
+    CAPI_GUARD_BEGIN
+    if (!d_allowed_ids && n_allowed) return fail(HNSWGPU_ERR_ARG, "null filter");
+    uint32_t panics = 0;
+    // an empty filter still is a filter (every point is refused); a null pointer would read as "no filter" below, so
+    // hand over a non-null pointer that is never dereferenced (n_allowed == 0)
+    const uint64_t* ids = d_allowed_ids ? d_allowed_ids : reinterpret_cast<const uint64_t*>(d_queries);
+    int rc = search_device_common(cidx, d_queries, nq, d, k, ef, ids, n_allowed, d_out_ids, d_out_dists, d_out_layer, d_out_rank,
+                                  d_out_counts, d_stats, stream, &panics);
+    if (n_panics) *n_panics = panics;
+    return rc;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
+static DeviceIndex* any_replica(hnswgpu_index* idx) {
+    if (idx->primary >= 0 && idx->replica(idx->primary)) return idx->replica(idx->primary);
+    return nullptr;
+}
 int hnswgpu_last_kernel_ms(const hnswgpu_index* cidx, double* ms, uint32_t* launches) {
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
-    if (!idx || !idx->dev) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
-    if (ms) *ms = idx->dev->last_kernel_ms();
-    if (launches) *launches = idx->dev->last_launches();
+    if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
+    std::shared_lock<std::shared_mutex> g(idx->mu);
+    DeviceIndex* dev = any_replica(idx);
+    if (!dev) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
+    const CallInfo c = dev->last_call();
+    if (ms) *ms = c.ms;
+    if (launches) *launches = c.launches;
     return HNSWGPU_OK;
 }
-
 int hnswgpu_last_search_kernel_ms(const hnswgpu_index* cidx, double* ms) {
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
-    if (!idx || !idx->dev || !ms) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
-    *ms = idx->dev->last_main_kernel_ms();
+    if (!idx || !ms) return fail(HNSWGPU_ERR_ARG, "null argument");
+    std::shared_lock<std::shared_mutex> g(idx->mu);
+    DeviceIndex* dev = any_replica(idx);
+    if (!dev) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
+    *ms = dev->last_call().main_ms;
     return HNSWGPU_OK;
 }
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on) {
     if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     idx->strict_ties = on != 0;
-    if (idx->dev) idx->dev->set_strict_ties(idx->strict_ties);
+    for (auto& kv : idx->replicas) kv.second->set_strict_ties(idx->strict_ties != 0);
     return HNSWGPU_OK;
 }
 int hnswgpu_last_tie_count(const hnswgpu_index* cidx, uint32_t* ties) {
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
-    if (!idx || !idx->dev || !ties) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
-    *ties = idx->dev->last_ties();
+    if (!idx || !ties) return fail(HNSWGPU_ERR_ARG, "null argument");
+    std::shared_lock<std::shared_mutex> g(idx->mu);
+    DeviceIndex* dev = any_replica(idx);
+    if (!dev) return fail(HNSWGPU_ERR_DEVICE, "index is not resident on a device");
+    *ties = dev->last_call().ties;
     return HNSWGPU_OK;
 }
 
 int hnswgpu_eval_distances(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out) {
+    CAPI_GUARD_BEGIN
     if (!a || !b || !out || dist < 0 || dist > 3) return fail(HNSWGPU_ERR_ARG, "bad argument");
     std::string err;
-    int rc = eval_distances_device(dist, a, b, n, d, out, err);
+    int rc = eval_distance_matrix_device(dist, a, n, b, n, d, 1, true, out, err);
     if (rc != OK) return fail(rc, err);
     return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
+                                 uint32_t batch, float* out) {
+    CAPI_GUARD_BEGIN
+    if (!queries || !rows || !out || dist < 0 || dist > 3) return fail(HNSWGPU_ERR_ARG, "bad argument");
+    std::string err;
+    int rc = eval_distance_matrix_device(dist, queries, nq, rows, n, d, batch, false, out, err);
+    if (rc != OK) return fail(rc, err);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
 }
 
 // =========================================================================================
@@ -318,21 +559,25 @@ struct HnswApif32 {
 };
 
 const HnswIo* get_hnswio(uint64_t flen, const uint8_t* name) {  // directory is always "." (src/libext.rs:31)
+    CAPI_GUARD_BEGIN
     if (!name) return nullptr;
     HnswIo* io = new HnswIo();
     io->dir = ".";
     io->basename.assign(reinterpret_cast<const char*>(name), (size_t)flen);
     return io;
+    CAPI_GUARD_END(nullptr)
 }
 void hnswgpu_free_hnswio(const HnswIo* p) { delete p; }
 
 static const HnswApif32* load_with(HnswIo* io, int dist) {
+    CAPI_GUARD_BEGIN
     if (!io) return nullptr;
     hnswgpu_index* idx = nullptr;
     if (hnswgpu_load_dump(io->dir.c_str(), io->basename.c_str(), dist, &idx) != HNSWGPU_OK) return nullptr;  // null on failure (:298-301)
     HnswApif32* api = new HnswApif32();
     api->idx = idx;
     return api;
+    CAPI_GUARD_END(nullptr)
 }
 const HnswApif32* load_hnswdump_f32_DistL1(HnswIo* io) { return load_with(io, HNSWGPU_DIST_L1); }
 const HnswApif32* load_hnswdump_f32_DistL2(HnswIo* io) { return load_with(io, HNSWGPU_DIST_L2); }
@@ -341,6 +586,7 @@ const HnswApif32* load_hnswdump_f32_DistDot(HnswIo* io) { return load_with(io, H
 
 static const HnswApif32* new_api(size_t max_nb_conn, size_t ef_const, size_t namelen, const uint8_t* cdistname,
                                  size_t max_elements, size_t max_layer, bool allow_cosine) {
+    CAPI_GUARD_BEGIN
     (void)max_elements;
     if (!cdistname) return nullptr;
     std::string dname(reinterpret_cast<const char*>(cdistname), namelen);
@@ -364,6 +610,7 @@ static const HnswApif32* new_api(size_t max_nb_conn, size_t ef_const, size_t nam
     HnswApif32* api = new HnswApif32();
     api->idx = idx;
     return api;
+    CAPI_GUARD_END(nullptr)
 }
 const HnswApif32* init_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namelen, const uint8_t* cdistname) {
     return new_api(max_nb_conn, ef_const, namelen, cdistname, 10000, 16, false);  // Hnsw::new(M, 10000, 16, ef_c, D) (:475)
@@ -373,30 +620,30 @@ const HnswApif32* new_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namel
     return new_api(max_nb_conn, ef_const, namelen, cdistname, max_elements, max_layer, false);
 }
 
+// The reference's insert_f32 / parallel_insert_f32 return nothing (:661-723).  They work on every handle, reloaded ones
+// included; a failure (dimension mismatch, ...) leaves the index unchanged and is readable through hnswgpu_last_error().
 void insert_f32(HnswApif32* api, size_t len, const float* data, size_t id) {
-    if (!api || !api->idx || !api->idx->builder || !data) return;
+    CAPI_GUARD_BEGIN
+    if (!api || !api->idx || !data) { fail(HNSWGPU_ERR_ARG, "insert_f32: null argument"); return; }
     hnswgpu_index* idx = api->idx;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     uint64_t id64 = id;
-    std::string err;
-    if (idx->builder->insert_batch(data, 1, len, &id64, 1, err) != OK) { fail(HNSWGPU_ERR_ARG, err); return; }
-    idx->flat_stale = true;
-    idx->dev_stale = true;
+    (void)insert_points(idx, data, 1, len, &id64, 1);
+    CAPI_GUARD_END()
 }
 void parallel_insert_f32(HnswApif32* api, size_t nb_vec, size_t vec_len, const float** datas, const size_t* ids) {
-    if (!api || !api->idx || !api->idx->builder || !datas || !ids) return;
+    CAPI_GUARD_BEGIN
+    if (!api || !api->idx || !datas || !ids) { fail(HNSWGPU_ERR_ARG, "parallel_insert_f32: null argument"); return; }
     hnswgpu_index* idx = api->idx;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::unique_lock<std::shared_mutex> g(idx->mu);
     std::vector<float> flat(nb_vec * vec_len);  // inputs are copied, like the reference (:700-712)
     std::vector<uint64_t> id64(nb_vec);
     for (size_t i = 0; i < nb_vec; ++i) {
         std::memcpy(flat.data() + i * vec_len, datas[i], vec_len * sizeof(float));
         id64[i] = ids[i];
     }
-    std::string err;
-    if (idx->builder->insert_batch(flat.data(), nb_vec, vec_len, id64.data(), 0, err) != OK) { fail(HNSWGPU_ERR_ARG, err); return; }
-    idx->flat_stale = true;
-    idx->dev_stale = true;
+    (void)insert_points(idx, flat.data(), nb_vec, vec_len, id64.data(), 0);
+    CAPI_GUARD_END()
 }
 
 static Neighbour_api* make_row(const uint64_t* ids, const float* dists, uint32_t cnt) {
@@ -410,6 +657,7 @@ static Neighbour_api* make_row(const uint64_t* ids, const float* dists, uint32_t
 
 const Neighbourhood_api* search_neighbours_f32(const HnswApif32* api, size_t len, const float* data, size_t knbn,
                                                size_t ef_search) {
+    CAPI_GUARD_BEGIN
     if (!api || !api->idx || !data || knbn == 0) return nullptr;
     std::vector<uint64_t> ids(knbn);
     std::vector<float> dists(knbn);
@@ -420,10 +668,12 @@ const Neighbourhood_api* search_neighbours_f32(const HnswApif32* api, size_t len
     ans->nbgh = cnt;
     ans->neighbours = make_row(ids.data(), dists.data(), cnt);
     return ans;
+    CAPI_GUARD_END(nullptr)
 }
 
 const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* api, size_t nb_vec, int64_t vec_len,
                                                             const float** data, size_t knbn, size_t ef_search) {
+    CAPI_GUARD_BEGIN
     if (!api || !api->idx || !data || knbn == 0 || vec_len <= 0) return nullptr;
     // array-of-pointers input is copied into one matrix (the reference copies into Vec<Vec<f32>>, :218-226)
     std::vector<float> q((size_t)nb_vec * (size_t)vec_len);
@@ -443,6 +693,7 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
     ans->len = (int64_t)nb_vec;
     ans->ptr = lists;
     return ans;
+    CAPI_GUARD_END(nullptr)
 }
 
 void hnswgpu_free_neighbourhood(const Neighbourhood_api* p) {
@@ -458,9 +709,11 @@ void hnswgpu_free_neighbourhood_vec(const Vec_api_Neighbourhood* p) {
 }
 
 int64_t file_dump_f32(const HnswApif32* api, size_t namelen, const uint8_t* filename) {
+    CAPI_GUARD_BEGIN
     if (!api || !api->idx || !filename) return -1;
     std::string base(reinterpret_cast<const char*>(filename), namelen);
     return hnswgpu_file_dump(api->idx, ".", base.c_str()) == HNSWGPU_OK ? 1 : -1;  // 1 / -1 (:269-272)
+    CAPI_GUARD_END(-1)
 }
 
 void drop_hnsw_f32(const HnswApif32* p) {
@@ -470,6 +723,7 @@ void drop_hnsw_f32(const HnswApif32* p) {
 }
 
 const DescriptionFFI* load_hnsw_description(size_t flen, const uint8_t* name) {
+    CAPI_GUARD_BEGIN
     if (!name) return nullptr;
     std::string path(reinterpret_cast<const char*>(name), flen);
     DumpDescription d;
@@ -494,6 +748,7 @@ const DescriptionFFI* load_hnsw_description(size_t flen, const uint8_t* name) {
     f->t_name_len = d.t_name.size();
     f->t_name = reinterpret_cast<const uint8_t*>(tn);
     return f;
+    CAPI_GUARD_END(nullptr)
 }
 void hnswgpu_free_description(const DescriptionFFI* p) {
     if (!p) return;

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -153,7 +154,11 @@ int load_dump(const std::string& dir, const std::string& basename, int asked_dis
     out.format_version = descr.format_version;
     out.dumpmode = descr.dumpmode;
     out.max_nb_connection = descr.max_nb_connection;
-    out.level_scale = descr.level_scale;
+    // Reference quirk, kept: the dump stores the generator's ABSOLUTE scale (get_level_scale(),
+    // src/hnswio.rs:1365-1371), and the reload hands it to LayerGenerator::new_with_scale as a FACTOR of 1/ln(M)
+    // (src/hnswio.rs:773-777, src/hnsw.rs:339-352).  A reloaded index therefore draws the levels of further points with,
+    // and dumps again, level_scale / ln(M).
+    out.level_scale = descr.level_scale / std::log((double)std::max<uint64_t>(2, descr.max_nb_connection));
     out.nb_layer = descr.nb_layer;
     out.ef_construction = descr.ef;
     out.dimension = descr.dimension;
@@ -166,7 +171,14 @@ int load_dump(const std::string& dir, const std::string& basename, int asked_dis
     uint8_t nb_layer = g.get<uint8_t>();
     if (!g.ok) { err = "truncated graph file"; return ERR_FORMAT; }
     if (nb_layer > NB_LAYER_MAX) { err = "inconsistent number of layers"; return ERR_FORMAT; }
-    const uint64_t n_hint = descr.nb_point;
+    // The header fields are untrusted (a truncated or corrupt file must give ERR_FORMAT, not a length_error thrown
+    // across the C ABI): reserves are bounded by what the two mapped files can actually hold -- a point record is at
+    // least 17 + 8 * nb_layer bytes of graph file and 20 + 4 d bytes of data file, an edge is 17 bytes.
+    if (d == 0 || d > (df.size / sizeof(float))) { err = "data dimension incoherent with the data file size"; return ERR_FORMAT; }
+    const uint64_t n_hint = std::min<uint64_t>({descr.nb_point, (uint64_t)gf.size / (17u + 8u * (uint64_t)descr.nb_layer),
+                                                (uint64_t)df.size / (20u + 4u * d)});
+    const uint64_t edge_hint = std::min<uint64_t>((uint64_t)gf.size / 17u,
+                                                  n_hint * 2 * std::max<uint64_t>(1, descr.max_nb_connection));
     out.origin_id.reserve(n_hint);
     out.vectors.reserve(n_hint * d);
     out.nbr_ptr.reserve(n_hint * NB_LAYER_MAX + 1);
@@ -174,10 +186,10 @@ int load_dump(const std::string& dir, const std::string& basename, int asked_dis
     // neighbours are first kept as packed (layer<<32 | rank): a neighbour may live in a layer that
     // comes later in the file, so flat ids are resolved once all layer counts are known.
     std::vector<uint64_t> nbr_packed;
-    nbr_packed.reserve(n_hint * 2 * std::max<uint64_t>(1, descr.max_nb_connection));
-    out.nbr_dist.reserve(nbr_packed.capacity());
+    nbr_packed.reserve(edge_hint);
+    out.nbr_dist.reserve(edge_hint);
     std::vector<uint64_t> nbr_origin;  // kept for the coherence check only
-    nbr_origin.reserve(nbr_packed.capacity());
+    nbr_origin.reserve(edge_hint);
 
     uint64_t n = 0;
     for (unsigned l = 0; l < nb_layer; ++l) {
@@ -216,7 +228,7 @@ int load_dump(const std::string& dir, const std::string& basename, int asked_dis
             if (dt.get<uint64_t>() != origin) { err = "origin_id incoherent between graph and data"; return ERR_FORMAT; }
             uint64_t slen = dt.get<uint64_t>();
             const uint8_t* raw = dt.bytes(slen);
-            if (!dt.ok || slen < d * sizeof(float)) { err = "truncated data file"; return ERR_FORMAT; }
+            if (!dt.ok || slen / sizeof(float) < d) { err = "truncated data file"; return ERR_FORMAT; }
             out.origin_id.push_back(origin);
             size_t off = out.vectors.size();
             out.vectors.resize(off + d);

@@ -8,7 +8,9 @@
 //   Hnsw::search_filter(None)      src/hnsw.rs:1487-1580   -> descent prologue + result epilogue
 //   Hnsw::search_layer             src/hnsw.rs:922-1064    -> expansion loop (visited set in LDS, ef-bounded
 //                                                             result/candidate set in VGPRs; literal BinaryHeaps
-//                                                             for the queries that meet an exact f32 tie)
+//                                                             where equal f32 distances make the reference's
+//                                                             decisions depend on heap order)
+//   Hnsw::search_filter(Some(&Vec<usize>))                 -> hnsw_search_exact_kernel with an allow bitmap
 //   Distance<f32>::eval            anndists 0.1            -> batch_dist<METRIC>: rows read by groups of lanes, each
 //                                                             distance summed left to right exactly like the
 //                                                             crate's scalar build (bit-identical)
@@ -34,18 +36,6 @@ namespace hnswgpu {
 
 namespace {
 
-#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
-// DistCosine's third sum for every point, once: f32 squares widened to f64, summed left to right (padding adds 0.0)
-__global__ void row_sq_norms_kernel(const float* __restrict__ vec, double* __restrict__ out, uint32_t n, uint32_t row_stride) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = vec + (size_t)i * row_stride;
-    double s2 = 0.;
-    for (uint32_t c = 0; c < row_stride; ++c) s2 = s2 + (double)(r[c] * r[c]);
-    out[i] = s2;
-}
-#endif
-
 // queries [nq][d] -> [nq][row_stride] zero padded
 __global__ void pad_queries_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t nq, uint32_t d,
                                    uint32_t row_stride) {
@@ -55,7 +45,6 @@ __global__ void pad_queries_kernel(const float* __restrict__ src, float* __restr
         dst[i] = c < d ? src[(size_t)r * d + c] : 0.f;
     }
 }
-
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -91,7 +80,6 @@ uint32_t ceil_log2(uint64_t x) {
     return b;
 }
 
-
 const KernelSet& kernel_set(int metric) {
     switch (metric) {
         case DIST_L2: return kernels_l2();
@@ -101,7 +89,91 @@ const KernelSet& kernel_set(int metric) {
     }
 }
 
+// device buffer grown on demand; a failed allocation leaves it empty (pointer AND capacity), never half valid
+struct DevBuf {
+    void* p = nullptr;
+    uint64_t cap = 0;
+    hipError_t ensure(uint64_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = bytes;
+        return hipSuccess;
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
 }  // namespace
+
+// everything one search call writes: taken from the replica's pool for the duration of the call
+struct DeviceIndex::Workspace {
+    DevBuf qpad, tie, predist, order, retry[2], stats, bitmap, heaps, cand, oplog, allow, allowed_ids, hostio[5];
+    void* d_ctrl = nullptr;   // work counter + counters
+    void* h_ctrl = nullptr;   // pinned host copy (read back once per launch)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_ks = nullptr, ev_ke = nullptr;
+    hipStream_t own_stream = nullptr;  // for the host-buffer entry points
+    int init(std::string& err) {
+        HIP_TRY(hipMalloc(&d_ctrl, 64));
+        HIP_TRY(hipHostMalloc(&h_ctrl, 64, hipHostMallocDefault));
+        HIP_TRY(hipEventCreate(&ev_start));
+        HIP_TRY(hipEventCreate(&ev_stop));
+        HIP_TRY(hipEventCreate(&ev_ks));
+        HIP_TRY(hipEventCreate(&ev_ke));
+        HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+        return OK;
+    }
+    ~Workspace() {
+        for (DevBuf* b : {&qpad, &tie, &predist, &order, &retry[0], &retry[1], &stats, &bitmap, &heaps, &cand, &oplog, &allow,
+                          &allowed_ids, &hostio[0], &hostio[1], &hostio[2], &hostio[3], &hostio[4]})
+            b->free();
+        if (d_ctrl) (void)hipFree(d_ctrl);
+        if (h_ctrl) (void)hipHostFree(h_ctrl);
+        for (hipEvent_t e : {ev_start, ev_stop, ev_ks, ev_ke})
+            if (e) (void)hipEventDestroy(e);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+};
+
+class DeviceIndex::Lease {
+public:
+    Lease(DeviceIndex* o, Workspace* w) : o_(o), w_(w) {}
+    ~Lease() { if (w_) o_->release_ws(w_); }
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
+    Workspace* get() const { return w_; }
+private:
+    DeviceIndex* o_;
+    Workspace* w_;
+};
+
+DeviceIndex::Workspace* DeviceIndex::acquire(std::string& err) {
+    {
+        std::lock_guard<std::mutex> g(pool_mu_);
+        if (!free_ws_.empty()) {
+            Workspace* w = free_ws_.back();
+            free_ws_.pop_back();
+            return w;
+        }
+    }
+    std::unique_ptr<Workspace> w(new Workspace());
+    if (w->init(err) != OK) return nullptr;
+    std::lock_guard<std::mutex> g(pool_mu_);
+    all_ws_.push_back(std::move(w));
+    return all_ws_.back().get();
+}
+void DeviceIndex::release_ws(Workspace* w) {
+    std::lock_guard<std::mutex> g(pool_mu_);
+    free_ws_.push_back(w);
+}
 
 int device_count() {
     int n = 0;
@@ -109,26 +181,32 @@ int device_count() {
     return n;
 }
 
+DeviceIndex::DeviceIndex() = default;
 DeviceIndex::~DeviceIndex() { release(); }
 
 void DeviceIndex::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_nrm2_, &d_qpad_, &d_ctrl_, &d_retry_[0], &d_retry_[1],
-                     &d_stats_, &d_bitmap_, &d_tie_, &d_heaps_, &d_cand_, &d_predist_, &d_order_, &d_hostio_[0], &d_hostio_[1], &d_hostio_[2], &d_hostio_[3], &d_hostio_[4]};
+    {
+        std::lock_guard<std::mutex> g(pool_mu_);
+        free_ws_.clear();
+        all_ws_.clear();
+    }
+    void** ptrs[] = {&d_vec_, &d_nbr0_, &d_up_ptr_, &d_up_ids_, &d_origin_, &d_nrm2_};
     for (void** p : ptrs)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
-    if (h_ctrl_) { (void)hipHostFree(h_ctrl_); h_ctrl_ = nullptr; }
-    if (ev_start_) { (void)hipEventDestroy((hipEvent_t)ev_start_); ev_start_ = nullptr; }
-    if (ev_stop_) { (void)hipEventDestroy((hipEvent_t)ev_stop_); ev_stop_ = nullptr; }
-    if (ev_mid_) { (void)hipEventDestroy((hipEvent_t)ev_mid_); ev_mid_ = nullptr; }
-    if (ev_ks_) { (void)hipEventDestroy((hipEvent_t)ev_ks_); ev_ks_ = nullptr; }
-    if (ev_ke_) { (void)hipEventDestroy((hipEvent_t)ev_ke_); ev_ke_ = nullptr; }
     ready_ = false;
 }
 
+CallInfo DeviceIndex::last_call() const {
+    std::lock_guard<std::mutex> g(meta_mu_);
+    return last_;
+}
+
 int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
-    if (const char* e = std::getenv("HNSWGPU_STRICT_TIES")) strict_ties_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("HNSWGPU_STRICT_TIES")) strict_ties_.store(std::atoi(e) != 0);
     if (x.n == 0 || x.entry_flat == NO_POINT) { err = "cannot upload an empty index"; return ERR_EMPTY; }
+    // bit 31 of a flat id is the EXPANDED flag of the result set
+    if (x.n >= 0x80000000ull) { err = "index too large for the device path (2^31 points or more)"; return ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device visible (a gfx950 GPU is required; there is no CPU fallback)"; return ERR_DEVICE; }
     if (device < 0 || device >= ndev) { err = "bad device ordinal"; return ERR_ARG; }
@@ -139,6 +217,7 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     num_cu_ = prop.multiProcessorCount;
     device_ = device;
     dist_ = x.dist;
+    bytes_ = 0;
 
     const uint64_t n = x.n, d = x.dimension;
     DeviceIndexView v{};
@@ -202,29 +281,12 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     HIP_TRY(hipMalloc(&d_origin_, n * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(d_origin_, x.origin_id.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
     bytes_ += n * sizeof(uint64_t);
-#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
-    if (x.dist == DIST_COSINE) {
+    if (x.dist == DIST_COSINE) {  // DistCosine's per-point sum of squares, once
         HIP_TRY(hipMalloc(&d_nrm2_, n * sizeof(double)));
-        hipLaunchKernelGGL(row_sq_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, static_cast<const float*>(d_vec_),
-                           static_cast<double*>(d_nrm2_), (uint32_t)n, v.row_stride);
+        HIP_TRY(launch_row_sq_norms(nullptr, static_cast<const float*>(d_vec_), static_cast<double*>(d_nrm2_), (uint32_t)n, v.row_stride));
         HIP_TRY(hipDeviceSynchronize());
         bytes_ += n * sizeof(double);
     }
-#endif
-    HIP_TRY(hipMalloc(&d_ctrl_, 64));
-    HIP_TRY(hipHostMalloc(&h_ctrl_, 64, hipHostMallocDefault));
-    hipEvent_t e0, e1, e2;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventCreate(&e2));
-    ev_start_ = e0;
-    ev_stop_ = e1;
-    ev_mid_ = e2;
-    hipEvent_t e3, e4;
-    HIP_TRY(hipEventCreate(&e3));
-    HIP_TRY(hipEventCreate(&e4));
-    ev_ks_ = e3;
-    ev_ke_ = e4;
 
     v.vec = static_cast<const float*>(d_vec_);
     v.nbr0 = static_cast<const uint32_t*>(d_nbr0_);
@@ -232,89 +294,153 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     v.up_ids = static_cast<const uint32_t*>(d_up_ids_);
     v.origin_id = static_cast<const uint64_t*>(d_origin_);
     v_ = v;
+    {
+        std::lock_guard<std::mutex> g(meta_mu_);
+        adapt_ef_ = 0;
+        adapt_tbits_ = 0;
+        last_ = CallInfo{};
+    }
     ready_ = true;
     return OK;
 }
 
-int DeviceIndex::ensure_workspace(uint64_t nq, uint64_t /*k*/, std::string& err) {
-    const uint64_t qpad_need = nq * v_.row_stride * sizeof(float);
-    if (qpad_need > qpad_cap_) {
-        if (d_qpad_) (void)hipFree(d_qpad_);
-        d_qpad_ = nullptr;
-        HIP_TRY(hipMalloc(&d_qpad_, qpad_need));
-        qpad_cap_ = qpad_need;
-    }
-    if (nq > tie_cap_) {
-        if (d_tie_) (void)hipFree(d_tie_);
-        d_tie_ = nullptr;
-        HIP_TRY(hipMalloc(&d_tie_, nq * sizeof(uint32_t)));
-        tie_cap_ = nq;
-    }
-    if (nq > sched_cap_) {
-        for (void** p : {&d_predist_, &d_order_}) {
-            if (*p) (void)hipFree(*p);
-            *p = nullptr;
-        }
-        sched_cap_ = 0;
-        HIP_TRY(hipMalloc(&d_predist_, nq * sizeof(float)));
-        HIP_TRY(hipMalloc(&d_order_, nq * sizeof(uint32_t)));
-        sched_cap_ = nq;
-    }
-    if (nq > retry_cap_) {
-        for (int i = 0; i < 2; ++i) {
-            if (d_retry_[i]) (void)hipFree(d_retry_[i]);
-            d_retry_[i] = nullptr;
-            HIP_TRY(hipMalloc(&d_retry_[i], nq * sizeof(uint32_t)));
-        }
-        retry_cap_ = nq;
-    }
-    if (nq * 8 * sizeof(uint32_t) > stats_cap_) {
-        if (d_stats_) (void)hipFree(d_stats_);
-        d_stats_ = nullptr;
-        HIP_TRY(hipMalloc(&d_stats_, nq * 8 * sizeof(uint32_t)));
-        stats_cap_ = nq * 8 * sizeof(uint32_t);
-    }
+// Literal search (hnsw_search_exact_kernel) of the queries in d_qlist (nullptr: all nq), optionally filtered.
+int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_qlist, uint32_t nq, uint64_t k, uint64_t ef,
+                           const uint32_t* d_allow, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
+                           int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* stats, void* stream_v, uint32_t* panics,
+                           std::string& err) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
+    const uint32_t bitmap_words = (v_.n + 31) / 32;
+    const uint64_t bm_slice = (uint64_t)bitmap_words * sizeof(uint32_t);
+    const uint64_t cand_cap = v_.n;                                   // every point is accepted at most once
+    const uint64_t heap_stride = ef + 2 + cand_cap;
+    const uint64_t per_block = bm_slice + heap_stride * sizeof(hent_t);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(1, (8ull << 30) / per_block));
+    grid = std::min<uint32_t>(grid, (uint32_t)num_cu_ * 4u);
+    HIP_TRY(w.bitmap.ensure((uint64_t)grid * bm_slice));
+    HIP_TRY(w.heaps.ensure((uint64_t)grid * heap_stride * sizeof(hent_t)));
+    SearchArgs a{};
+    a.queries = d_qpad;
+    a.qlist = d_qlist;
+    a.nq = nq;
+    a.k = (uint32_t)k;
+    a.ef = (uint32_t)ef;
+    a.tile_bytes = tile_bytes;
+    a.work_counter = static_cast<uint32_t*>(w.d_ctrl);
+    a.overflow_count = static_cast<uint32_t*>(w.d_ctrl) + 1;
+    a.bitmap = w.bitmap.as<uint32_t>();
+    a.bitmap_words = bitmap_words;
+    a.bitmap_blocks = grid;
+    a.nrm2 = static_cast<const double*>(d_nrm2_);
+    a.out_ids = d_out_ids;
+    a.out_dists = d_out_dists;
+    a.out_layer = d_out_layer;
+    a.out_rank = d_out_rank;
+    a.out_counts = d_out_counts;
+    a.stats = stats;
+    ExactArgs x{};
+    x.heaps = w.heaps.as<hent_t>();
+    x.heap_stride = heap_stride;
+    x.cand_cap = (uint32_t)std::min<uint64_t>(cand_cap, 0xFFFFFFFFull);
+    x.allow = d_allow;
+    // heaps' top levels in LDS: up to ~56 KiB per workgroup (this kernel is latency-, not occupancy-bound)
+    const uint64_t lds_budget = 56 * 1024 - (tile_bytes + IDS_BYTES);
+    x.r_lds_cap = (uint32_t)std::min<uint64_t>(ef + 2, lds_budget / 2 / sizeof(hent_t));
+    x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
+    HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, 16, stream));
+    const size_t lds = tile_bytes + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
+    const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
+    HIP_TRY(kernel_set(dist_).launch_exact(ns, grid, lds, stream, v_, a, x));
+    volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);
+    HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(wait_stream(stream));
+    if (ctrl[1] != 0) { err = "internal error in the literal search kernel (candidate heap overflow or a refused point inside return_points)"; return ERR_DEVICE; }
+    if (panics) *panics = ctrl[2];
     return OK;
 }
 
 int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_arg,
                                uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank,
-                               uint32_t* d_out_counts, uint32_t* d_stats, void* stream_v, std::string& err) {
+                               uint32_t* d_out_counts, uint32_t* d_stats, void* stream_v, const uint64_t* d_allowed,
+                               uint64_t n_allowed, CallInfo* info_out, std::string& err) {
     if (!ready_) { err = "index is not resident on a device: call hnswgpu_upload first"; return ERR_DEVICE; }
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
-    if (nq == 0) { last_ms_ = 0; last_launches_ = 0; return OK; }
+    CallInfo info{};
+    auto publish = [&]() {
+        if (info_out) *info_out = info;
+        std::lock_guard<std::mutex> g(meta_mu_);
+        last_ = info;
+    };
+    if (nq == 0) { publish(); return OK; }
     if (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts) { err = "null buffer"; return ERR_ARG; }
     if (k == 0) { err = "knbn must be > 0"; return ERR_ARG; }
     const uint64_t ef = std::max(ef_arg, k);  // src/hnsw.rs:1531
-    if (ef > 1024) { err = "ef (= max(ef, knbn)) above 1024 is not supported by the register-resident result set"; return ERR_ARG; }
+    if (ef > 0x7FFFFFF0ull) { err = "ef too large"; return ERR_ARG; }
     if (nq > 0xFFFFFFF0ull) { err = "too many queries in one batch"; return ERR_ARG; }
+    const bool filtered = d_allowed != nullptr || n_allowed != 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     HIP_TRY(hipSetDevice(device_));
-    int rc = ensure_workspace(nq, k, err);
-    if (rc != OK) return rc;
-    uint32_t* stats = d_stats ? d_stats : static_cast<uint32_t*>(d_stats_);
+    Lease lease(this, acquire(err));
+    if (!lease.get()) return ERR_DEVICE;
+    Workspace& w = *lease.get();
+
+    HIP_TRY(w.qpad.ensure(nq * v_.row_stride * sizeof(float)));
+    if (!d_stats) HIP_TRY(w.stats.ensure(nq * 8 * sizeof(uint32_t)));
+    uint32_t* stats = d_stats ? d_stats : w.stats.as<uint32_t>();
+    const bool strict_ties = strict_ties_.load();
+
+    HIP_TRY(hipEventRecord(w.ev_start, stream));
+    // pad queries to the row stride (tiny, stays on the launch stream)
+    {
+        const uint64_t total = nq * v_.row_stride;
+        const int blocks = (int)std::min<uint64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(pad_queries_kernel, dim3(blocks), dim3(256), 0, stream, d_queries, w.qpad.as<float>(), (uint32_t)nq, v_.d,
+                           v_.row_stride);
+    }
+
+    // ---- filtered search, and ef beyond the register-resident result set (64 x 16 entries): literal heaps in memory
+    if (filtered || ef > 1024) {
+        const uint32_t* d_allow = nullptr;
+        if (filtered) {
+            HIP_TRY(w.allow.ensure((uint64_t)((v_.n + 31) / 32) * sizeof(uint32_t)));
+            HIP_TRY(launch_allow_bitmap(stream, v_.origin_id, v_.n, d_allowed, n_allowed, w.allow.as<uint32_t>()));
+            d_allow = w.allow.as<uint32_t>();
+        }
+        HIP_TRY(hipEventRecord(w.ev_ks, stream));
+        int rc = run_exact(w, w.qpad.as<float>(), nullptr, (uint32_t)nq, k, ef, d_allow, d_out_ids, d_out_dists, d_out_layer, d_out_rank,
+                           d_out_counts, stats, stream, &info.panics, err);
+        if (rc != OK) return rc;
+        HIP_TRY(hipEventRecord(w.ev_stop, stream));
+        HIP_TRY(wait_event(w.ev_stop));
+        float ms = 0.f, ms_main = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev_start, w.ev_stop));
+        HIP_TRY(hipEventElapsedTime(&ms_main, w.ev_ks, w.ev_stop));
+        info.ms = ms;
+        info.main_ms = ms_main;
+        info.launches = 1;
+        publish();
+        return OK;
+    }
+
+    HIP_TRY(w.tie.ensure(nq * sizeof(uint32_t)));
+    HIP_TRY(w.retry[0].ensure(nq * sizeof(uint32_t)));
+    HIP_TRY(w.retry[1].ensure(nq * sizeof(uint32_t)));
 
     int slots = 1;
     while ((uint64_t)slots * 64 < ef) slots *= 2;
     if (slots == 8) slots = 16;  // kernels are instantiated for 1, 2, 4 and 16 result slots per lane
 
-    HIP_TRY(hipEventRecord((hipEvent_t)ev_start_, stream));
-    // pad queries to the row stride (tiny, stays on the launch stream)
-    {
-        const uint64_t total = nq * v_.row_stride;
-        const int blocks = (int)std::min<uint64_t>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(pad_queries_kernel, dim3(blocks), dim3(256), 0, stream, d_queries,
-                           static_cast<float*>(d_qpad_), (uint32_t)nq, v_.d, v_.row_stride);
-    }
-
     // Visited-set sizing.  LDS per wavefront is what bounds occupancy, so the table is sized for the
     // typical query (ef x degree cells, ~2.4x the median number of visited points, measured); the few
-    // per cent of queries that outgrow it start over on the HBM bitmap inside the same launch.
+    // per cent of queries that outgrow it move to the HBM bitmap inside the same launch.
     const uint32_t idbits = std::max<uint32_t>(1u, ceil_log2(v_.n));
     const uint64_t expect = ef * std::min<uint64_t>(v_.deg_stride, 64);
     uint32_t tbits = std::min<uint32_t>(14u, std::max<uint32_t>(8u, ceil_log2(expect)));
-    // ... then follows what the previous batches with the same ef measured (adapt_* below)
-    if (adapt_ef_ == ef && adapt_tbits_ != 0) tbits = adapt_tbits_;
+    {   // ... then follows what the previous batches with the same ef measured
+        std::lock_guard<std::mutex> g(meta_mu_);
+        if (adapt_ef_ == ef && adapt_tbits_ != 0) tbits = adapt_tbits_;
+    }
     bool env_forced = false;
     if (const char* e = std::getenv("HNSWGPU_HASH_BITS")) {  // tuning / test hook: initial table size
         int b = std::atoi(e);
@@ -330,20 +456,21 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     // long searches first (DESIGN.md "scheduling").  Small batches skip it (one launch, lowest latency).
     const bool scheduled = nq >= 256 && !std::getenv("HNSWGPU_NO_SCHED");
     if (scheduled) {
+        HIP_TRY(w.predist.ensure(nq * sizeof(float)));
+        HIP_TRY(w.order.ensure(nq * sizeof(uint32_t)));
         SearchArgs da{};
-        da.queries = static_cast<const float*>(d_qpad_);
+        da.queries = w.qpad.as<float>();
         da.nq = (uint32_t)nq;
-        da.pre_dist = static_cast<float*>(d_predist_);
+        da.pre_dist = w.predist.as<float>();
         const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)num_cu_ * 24u);
         HIP_TRY(kernel_set(dist_).launch_estimate(dgrid, stream, v_, da));
-        HIP_TRY(kernel_set(dist_).launch_order(stream, static_cast<const float*>(d_predist_), (uint32_t)nq, static_cast<uint32_t*>(d_order_)));
+        HIP_TRY(kernel_set(dist_).launch_order(stream, w.predist.as<float>(), (uint32_t)nq, w.order.as<uint32_t>()));
     }
     uint32_t launches = 0;
     uint32_t work = (uint32_t)nq;
-    uint32_t n_ties = 0, n_converted = 0;
-    const uint32_t* qlist = scheduled ? static_cast<const uint32_t*>(d_order_) : nullptr;
+    uint32_t n_flagged = 0, n_literal = 0;
+    const uint32_t* qlist = scheduled ? w.order.as<uint32_t>() : nullptr;
     int pingpong = 0;
-    SearchArgs last_args{};
     for (;;) {
         SearchArgs a{};
         size_t lds = lds_fixed;
@@ -360,28 +487,26 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             a.tbits = tb;
         }
         a.tile_bytes = tile_bytes;
-#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
         a.nrm2 = static_cast<const double*>(d_nrm2_);
-#endif
         a.idbits = idbits;
         const KernelSet& ks = kernel_set(dist_);
-        const bool strict_kernel = strict_ties_ && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
-        if (strict_kernel) {  // top levels of candidate_points for the queries that are answered by the literal heaps
-            a.cand_lds = 512;
+        const bool strict_kernel = strict_ties && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
+        if (strict_kernel) {  // top levels of the literal candidate heap, for the few queries that need it
+            a.cand_lds = 256;
             lds += (size_t)a.cand_lds * sizeof(hent_t);
         }
         int per_cu = 0;
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));
         if (per_cu < 1) per_cu = 1;
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
-        a.queries = static_cast<const float*>(d_qpad_);
+        a.queries = w.qpad.as<float>();
         a.qlist = qlist;
         a.nq = work;
         a.k = (uint32_t)k;
         a.ef = (uint32_t)ef;
-        a.work_counter = static_cast<uint32_t*>(d_ctrl_);
-        a.overflow_count = static_cast<uint32_t*>(d_ctrl_) + 1;
-        a.retry_out = static_cast<uint32_t*>(d_retry_[pingpong]);
+        a.work_counter = static_cast<uint32_t*>(w.d_ctrl);
+        a.overflow_count = static_cast<uint32_t*>(w.d_ctrl) + 1;
+        a.retry_out = w.retry[pingpong].as<uint32_t>();
         a.out_ids = d_out_ids;
         a.out_dists = d_out_dists;
         a.out_layer = d_out_layer;
@@ -394,78 +519,47 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             const uint64_t slice = (uint64_t)a.bitmap_words * sizeof(uint32_t);
             uint64_t blocks = std::min<uint64_t>(grid, std::max<uint64_t>(1, (4ull << 30) / slice));
             if (table == TABLE_GLOBAL_BITMAP) grid = (uint32_t)blocks;  // every workgroup needs one
-            const uint64_t need = blocks * slice;
-            if (need > bitmap_cap_) {
-                if (d_bitmap_) (void)hipFree(d_bitmap_);
-                d_bitmap_ = nullptr;
-                bitmap_cap_ = 0;
-                HIP_TRY(hipMalloc(&d_bitmap_, need));
-                bitmap_cap_ = need;
-            }
-            a.bitmap = static_cast<uint32_t*>(d_bitmap_);
+            HIP_TRY(w.bitmap.ensure(blocks * slice));
+            a.bitmap = w.bitmap.as<uint32_t>();
             a.bitmap_blocks = (uint32_t)blocks;
         }
-        a.tie_list = strict_ties_ ? static_cast<uint32_t*>(d_tie_) : nullptr;
+        a.tie_list = w.tie.as<uint32_t>();
         if (strict_kernel) {
-            // per-workgroup scratch for the part of candidate_points that does not fit in LDS
-            const uint32_t cap = 8192;
+            // per-workgroup scratch: the heap-operation log, and the part of the literal candidate heap beyond LDS
+            const uint32_t cap = 4096;
             const uint64_t need = (uint64_t)grid * cap * sizeof(hent_t);
-            if (need > strict_cap_) {
-                if (d_cand_) (void)hipFree(d_cand_);
-                d_cand_ = nullptr;
-                strict_cap_ = 0;
-                HIP_TRY(hipMalloc(&d_cand_, need));
-                strict_cap_ = need;
-            }
-            a.cand_scratch = static_cast<hent_t*>(d_cand_);
+            HIP_TRY(w.cand.ensure(need));
+            HIP_TRY(w.oplog.ensure(need));
+            a.cand_scratch = w.cand.as<hent_t>();
             a.cand_cap = cap;
-#if (defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME) || (defined(HNSW_EXACT_VALUE_R) && HNSW_EXACT_VALUE_R)
-            {   // experiment: heap-operation log of the first attempt (same size as the candidate scratch)
-                static void* d_oplog = nullptr;
-                static uint64_t oplog_bytes = 0;
-                if (need > oplog_bytes) {
-                    if (d_oplog) (void)hipFree(d_oplog);
-                    d_oplog = nullptr;
-                    oplog_bytes = 0;
-                    HIP_TRY(hipMalloc(&d_oplog, need));
-                    oplog_bytes = need;
-                }
-                a.oplog = static_cast<hent_t*>(d_oplog);
-                a.oplog_cap = cap;
-            }
-#endif
-            // most queries of the previous batch met a tie (integer-valued data does that): skip the first attempt
-            a.exact_first = (adapt_exact_ef_ == ef && adapt_exact_first_) ? 1u : 0u;
-            if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;
+            a.oplog = w.oplog.as<hent_t>();
+            a.oplog_cap = cap;
+            if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;  // test hook
         }
-        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, launches == 0 ? 32 : 16, stream));  // the tie list spans relaunches
-        if (launches == 0) HIP_TRY(hipEventRecord((hipEvent_t)ev_ks_, stream));
+        HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, launches == 0 ? 32 : 16, stream));  // the flagged list spans relaunches
+        if (launches == 0) HIP_TRY(hipEventRecord(w.ev_ks, stream));
         HIP_TRY(ks.launch_search(slots, table, strict_kernel, grid, lds, stream, v_, a));
-        if (launches == 0) HIP_TRY(hipEventRecord((hipEvent_t)ev_ke_, stream));
-        last_args = a;
+        if (launches == 0) HIP_TRY(hipEventRecord(w.ev_ke, stream));
         ++launches;
-        volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(h_ctrl_);  // pinned: a true asynchronous copy
-        HIP_TRY(hipMemcpyAsync(h_ctrl_, d_ctrl_, 24, hipMemcpyDeviceToHost, stream));
+        volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);  // pinned: a true asynchronous copy
+        HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 24, hipMemcpyDeviceToHost, stream));
         HIP_TRY(wait_stream(stream));
-        n_ties = ctrl[4];        // flagged for the replay kernel (cumulative over relaunches)
-        n_converted = ctrl[5];   // needed the literal heaps inside the launch
-        if (launches == 1 && strict_kernel && nq >= 256) {
-            adapt_exact_ef_ = ef;
-            adapt_exact_first_ = (uint64_t)n_converted * 2 > nq;
-        }
+        n_flagged = ctrl[4];     // not resolved in the launch (cumulative over relaunches)
+        n_literal += ctrl[5];    // resolved with the literal heaps inside the launch
         if (launches == 1 && table != TABLE_GLOBAL_BITMAP && !env_forced && nq >= 256) {
             // Table sizing feedback for the next batch: grow when more than ~1 query in 8 had to move to the
             // HBM bitmap, shrink when a half-size table would have overflowed for fewer than 1 in 32.
             uint32_t next = tbits_first;
             if ((uint64_t)ctrl[2] * 8 > nq && tbits_first < 14u) next = tbits_first + 1;
             else if ((uint64_t)ctrl[3] * 32 < nq && tbits_first > 8u) next = tbits_first - 1;
+            std::lock_guard<std::mutex> g(meta_mu_);
             adapt_ef_ = ef;
             adapt_tbits_ = next;
         }
         if (ctrl[1] == 0) break;
-        // some queries visited more points than the table holds: rerun only those
+        // some queries visited more points than the table holds and had no bitmap slice: rerun only those
         work = ctrl[1];
-        qlist = static_cast<const uint32_t*>(d_retry_[pingpong]);
+        qlist = w.retry[pingpong].as<uint32_t>();
         pingpong ^= 1;
         if (table == TABLE_GLOBAL_BITMAP) { err = "internal error: bitmap visited set reported an overflow"; return ERR_DEVICE; }
         if (!grown && tbits < 14u) {
@@ -475,126 +569,115 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             table = TABLE_GLOBAL_BITMAP;
         }
     }
-    last_ties_ = n_ties + n_converted;
-    HIP_TRY(hipEventRecord((hipEvent_t)ev_mid_, stream));  // end of the search kernel proper (before any exact replay)
-    if (strict_ties_ && n_ties > 0) {
-        // Exact replay of the tie-affected queries with literal binary heaps (hnsw_search_exact_kernel).
-        const uint64_t bm_slice = (uint64_t)last_args.bitmap_words * sizeof(uint32_t);
-        const uint64_t cand_cap = v_.n;                                   // every point is accepted at most once
-        const uint64_t heap_stride = ef + 2 + cand_cap;
-        const uint64_t per_block = bm_slice + heap_stride * sizeof(hent_t);
-        uint32_t grid = (uint32_t)std::min<uint64_t>(n_ties, std::max<uint64_t>(1, (2ull << 30) / per_block));
-        grid = std::min<uint32_t>(grid, (uint32_t)num_cu_ * 4u);
-        if ((uint64_t)grid * bm_slice > bitmap_cap_) {
-            if (d_bitmap_) (void)hipFree(d_bitmap_);
-            d_bitmap_ = nullptr;
-            bitmap_cap_ = 0;
-            HIP_TRY(hipMalloc(&d_bitmap_, (uint64_t)grid * bm_slice));
-            bitmap_cap_ = (uint64_t)grid * bm_slice;
-        }
-        if ((uint64_t)grid * heap_stride * sizeof(hent_t) > heaps_cap_) {
-            if (d_heaps_) (void)hipFree(d_heaps_);
-            d_heaps_ = nullptr;
-            heaps_cap_ = 0;
-            HIP_TRY(hipMalloc(&d_heaps_, (uint64_t)grid * heap_stride * sizeof(hent_t)));
-            heaps_cap_ = (uint64_t)grid * heap_stride * sizeof(hent_t);
-        }
-        SearchArgs a = last_args;
-        a.qlist = static_cast<const uint32_t*>(d_tie_);
-        a.nq = n_ties;
-        a.bitmap = static_cast<uint32_t*>(d_bitmap_);
-        a.tie_list = nullptr;
-        ExactArgs x{};
-        x.heaps = static_cast<hent_t*>(d_heaps_);
-        x.heap_stride = heap_stride;
-        x.cand_cap = (uint32_t)cand_cap;
-        // heaps' top levels in LDS: up to ~56 KiB per workgroup (the exact replay is latency-, not occupancy-bound)
-        const uint64_t lds_budget = 56 * 1024 - (tile_bytes + IDS_BYTES);
-        x.r_lds_cap = (uint32_t)std::min<uint64_t>(ef + 2, lds_budget / 2 / sizeof(hent_t));
-        x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
-        HIP_TRY(hipMemsetAsync(d_ctrl_, 0, 8, stream));
-        const size_t lds = tile_bytes + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
-        const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
-        HIP_TRY(kernel_set(dist_).launch_exact(ns, grid, lds, stream, v_, a, x));
+    info.ties = n_flagged + n_literal;
+    if (strict_ties && n_flagged > 0) {
+        // the flagged queries again, with both heaps literal from the first operation on
+        int rc = run_exact(w, w.qpad.as<float>(), w.tie.as<uint32_t>(), n_flagged, k, ef, nullptr, d_out_ids, d_out_dists, d_out_layer,
+                           d_out_rank, d_out_counts, stats, stream, nullptr, err);
+        if (rc != OK) return rc;
         ++launches;
-        volatile uint32_t* ctrl2 = static_cast<volatile uint32_t*>(h_ctrl_);
-        HIP_TRY(hipMemcpyAsync(h_ctrl_, d_ctrl_, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(wait_stream(stream));
-        if (ctrl2[1] != 0) { err = "internal error: candidate heap overflow in the exact replay"; return ERR_DEVICE; }
     }
-    HIP_TRY(hipEventRecord((hipEvent_t)ev_stop_, stream));
-    HIP_TRY(wait_event((hipEvent_t)ev_stop_));
+    HIP_TRY(hipEventRecord(w.ev_stop, stream));
+    HIP_TRY(wait_event(w.ev_stop));
     float ms = 0.f, ms_main = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, (hipEvent_t)ev_start_, (hipEvent_t)ev_stop_));
-    HIP_TRY(hipEventElapsedTime(&ms_main, (hipEvent_t)ev_ks_, (hipEvent_t)ev_ke_));  // first launch of the search kernel alone
-    last_ms_ = ms;
-    last_main_ms_ = ms_main;
-    last_launches_ = launches;
+    HIP_TRY(hipEventElapsedTime(&ms, w.ev_start, w.ev_stop));
+    HIP_TRY(hipEventElapsedTime(&ms_main, w.ev_ks, w.ev_ke));  // first launch of the search kernel alone
+    info.ms = ms;
+    info.main_ms = ms_main;
+    info.launches = launches;
+    publish();
     return OK;
 }
 
 int DeviceIndex::search_host(const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids,
                              float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
-                             std::string& err) {
+                             const uint64_t* allowed, uint64_t n_allowed, bool filtered, uint8_t* out_status,
+                             CallInfo* info, std::string& err) {
     if (!ready_) { err = "index is not resident on a device: call hnswgpu_upload first"; return ERR_DEVICE; }
-    if (nq == 0) return OK;
+    if (nq == 0) { if (info) *info = CallInfo{}; return OK; }
     if (!queries || !out_ids || !out_dists || !out_counts) { err = "null buffer"; return ERR_ARG; }
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
+    if (k == 0) { err = "knbn must be > 0"; return ERR_ARG; }
+    if (filtered && n_allowed && !allowed) { err = "null filter"; return ERR_ARG; }
     HIP_TRY(hipSetDevice(device_));
-    if (nq * d > hostio_cap_q_ || nq * k > hostio_cap_k_ || nq > hostio_cap_n_) {
-        for (auto& p : d_hostio_) {
-            if (p) (void)hipFree(p);
-            p = nullptr;
-        }
-        hostio_cap_q_ = hostio_cap_k_ = hostio_cap_n_ = 0;
-        HIP_TRY(hipMalloc(&d_hostio_[0], nq * d * sizeof(float)));
-        HIP_TRY(hipMalloc(&d_hostio_[1], nq * k * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&d_hostio_[2], nq * k * sizeof(float)));
-        HIP_TRY(hipMalloc(&d_hostio_[3], nq * k * (sizeof(int32_t) + 1)));
-        HIP_TRY(hipMalloc(&d_hostio_[4], nq * sizeof(uint32_t)));
-        hostio_cap_q_ = nq * d;
-        hostio_cap_k_ = nq * k;
-        hostio_cap_n_ = nq;
-    }
-    float* dq = static_cast<float*>(d_hostio_[0]);
-    uint64_t* dids = static_cast<uint64_t*>(d_hostio_[1]);
-    float* ddist = static_cast<float*>(d_hostio_[2]);
-    int32_t* drank = static_cast<int32_t*>(d_hostio_[3]);
+    // the staging buffers live in their own workspace: search_device takes a second one for its scratch
+    Lease lease(this, acquire(err));
+    if (!lease.get()) return ERR_DEVICE;
+    Workspace& w = *lease.get();
+    hipStream_t stream = w.own_stream;
+    HIP_TRY(w.hostio[0].ensure(nq * d * sizeof(float)));
+    HIP_TRY(w.hostio[1].ensure(nq * k * sizeof(uint64_t)));
+    HIP_TRY(w.hostio[2].ensure(nq * k * sizeof(float)));
+    HIP_TRY(w.hostio[3].ensure(nq * k * (sizeof(int32_t) + 1)));
+    HIP_TRY(w.hostio[4].ensure(nq * sizeof(uint32_t)));
+    HIP_TRY(w.stats.ensure(nq * 8 * sizeof(uint32_t)));
+    float* dq = w.hostio[0].as<float>();
+    uint64_t* dids = w.hostio[1].as<uint64_t>();
+    float* ddist = w.hostio[2].as<float>();
+    int32_t* drank = w.hostio[3].as<int32_t>();
     uint8_t* dlayer = reinterpret_cast<uint8_t*>(drank + nq * k);
-    uint32_t* dcnt = static_cast<uint32_t*>(d_hostio_[4]);
-    HIP_TRY(hipMemcpy(dq, queries, nq * d * sizeof(float), hipMemcpyHostToDevice));
-    int rc = search_device(dq, nq, d, k, ef, dids, ddist, dlayer, drank, dcnt, nullptr, nullptr, err);
+    uint32_t* dcnt = w.hostio[4].as<uint32_t>();
+    const uint64_t* dallowed = nullptr;
+    if (filtered) {
+        HIP_TRY(w.allowed_ids.ensure(std::max<uint64_t>(1, n_allowed) * sizeof(uint64_t)));
+        if (n_allowed) HIP_TRY(hipMemcpyAsync(w.allowed_ids.p, allowed, n_allowed * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        dallowed = w.allowed_ids.as<uint64_t>();
+    }
+    HIP_TRY(hipMemcpyAsync(dq, queries, nq * d * sizeof(float), hipMemcpyHostToDevice, stream));
+    int rc = search_device(dq, nq, d, k, ef, dids, ddist, dlayer, drank, dcnt, w.stats.as<uint32_t>(), stream, dallowed,
+                           filtered ? n_allowed : 0, info, err);
     if (rc != OK) return rc;
-    HIP_TRY(hipMemcpy(out_ids, dids, nq * k * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_dists, ddist, nq * k * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_layer) HIP_TRY(hipMemcpy(out_layer, dlayer, nq * k, hipMemcpyDeviceToHost));
-    if (out_rank) HIP_TRY(hipMemcpy(out_rank, drank, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_counts, dcnt, nq * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out_ids, dids, nq * k * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(out_dists, ddist, nq * k * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (out_layer) HIP_TRY(hipMemcpyAsync(out_layer, dlayer, nq * k, hipMemcpyDeviceToHost, stream));
+    if (out_rank) HIP_TRY(hipMemcpyAsync(out_rank, drank, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, dcnt, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    std::vector<uint32_t> st;
+    if (out_status) {
+        st.resize(nq * 8);
+        HIP_TRY(hipMemcpyAsync(st.data(), w.stats.p, nq * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (out_status)
+        for (uint64_t i = 0; i < nq; ++i) out_status[i] = st[i * 8 + 3] == 6u ? 1 : 0;
     return OK;
 }
 
-int eval_distances_device(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out, std::string& err) {
-    if (n == 0) return OK;
+int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
+                                uint32_t nf, bool pairs, float* out, std::string& err) {
+    if (nq == 0 || n == 0) return OK;
+    if (!pairs && (nf < 1 || nf > 64)) { err = "nf must be in 1..64"; return ERR_ARG; }
+    if (pairs && nq != n) { err = "pair mode needs as many queries as rows"; return ERR_ARG; }
+    if (!pairs && nq > 65535) { err = "too many queries for one launch"; return ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device visible"; return ERR_DEVICE; }
     const uint32_t rs = (uint32_t)((d + 31) / 32 * 32);
-    std::vector<float> pa((size_t)n * rs, 0.f), pb((size_t)n * rs, 0.f);
-    for (uint64_t i = 0; i < n; ++i) {
-        std::memcpy(pa.data() + i * rs, a + i * d, d * sizeof(float));
-        std::memcpy(pb.data() + i * rs, b + i * d, d * sizeof(float));
+    std::vector<float> pq((size_t)nq * rs, 0.f), pr((size_t)n * rs, 0.f);
+    for (uint64_t i = 0; i < nq; ++i) std::memcpy(pq.data() + i * rs, queries + i * d, d * sizeof(float));
+    for (uint64_t i = 0; i < n; ++i) std::memcpy(pr.data() + i * rs, rows + i * d, d * sizeof(float));
+    DevBuf dq, dr, dn, dout;
+    struct Free { DevBuf *a, *b, *c, *e; ~Free() { a->free(); b->free(); c->free(); e->free(); } } guard{&dq, &dr, &dn, &dout};
+    const uint64_t n_out = pairs ? n : nq * n;
+    HIP_TRY(dq.ensure(pq.size() * sizeof(float)));
+    HIP_TRY(dr.ensure(pr.size() * sizeof(float)));
+    HIP_TRY(dout.ensure(n_out * sizeof(float)));
+    HIP_TRY(hipMemcpy(dq.p, pq.data(), pq.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, pr.data(), pr.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (dist == DIST_COSINE) {
+        HIP_TRY(dn.ensure(n * sizeof(double)));
+        HIP_TRY(launch_row_sq_norms(nullptr, dr.as<float>(), dn.as<double>(), (uint32_t)n, rs));
     }
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&da, pa.size() * sizeof(float)));
-    HIP_TRY(hipMalloc(&db, pb.size() * sizeof(float)));
-    HIP_TRY(hipMalloc(&dout, n * sizeof(float)));
-    HIP_TRY(hipMemcpy(da, pa.data(), pa.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
-    const int blocks = (int)((n + 63) / 64);
-    HIP_TRY(kernel_set(dist).launch_eval_pairs((uint32_t)blocks, da, db, dout, (uint32_t)n, rs));
-    HIP_TRY(hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(da);
-    (void)hipFree(db);
-    (void)hipFree(dout);
+    if (pairs) {
+        for (uint64_t q0 = 0; q0 < n; q0 += 32768) {  // gridDim.y is limited to 65535
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>(32768, n - q0);
+            HIP_TRY(kernel_set(dist).launch_eval_matrix(nullptr, dq.as<float>() + q0 * rs, cnt, dr.as<float>() + q0 * rs, cnt,
+                                                        dist == DIST_COSINE ? dn.as<double>() + q0 : nullptr, dout.as<float>() + q0, rs, 1, true));
+        }
+    } else {
+        HIP_TRY(kernel_set(dist).launch_eval_matrix(nullptr, dq.as<float>(), (uint32_t)nq, dr.as<float>(), (uint32_t)n, dn.as<double>(),
+                                                    dout.as<float>(), rs, nf, false));
+    }
+    HIP_TRY(hipMemcpy(out, dout.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
     return OK;
 }
 

@@ -1,8 +1,12 @@
 // search_device.hpp -- HBM replica of a FlatIndex and the batched-search driver (host API of
 // search_device.hip).  Everything here needs a gfx950 device; there is no CPU fallback.
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <vector>
 #include "flat_index.hpp"
 
 namespace hnswgpu {
@@ -25,9 +29,21 @@ struct DeviceIndexView {
     uint32_t layer_offset[NB_LAYER_MAX + 1];
 };
 
+// What a search call reports about itself (the timings are HIP events on the launch stream).
+struct CallInfo {
+    double ms = 0.0;         // all kernels of the call
+    double main_ms = 0.0;    // first launch of the search kernel alone
+    uint32_t launches = 0;
+    uint32_t ties = 0;       // queries whose answer depended on the reference's heap order (resolved or flagged)
+    uint32_t panics = 0;     // filtered search: queries on which the reference panics (src/hnsw.rs:973)
+};
+
+// One replica of an index in the HBM of one device.  The replica is immutable after upload(); every search call takes
+// a private workspace (scratch buffers, events, counters) from a pool, so concurrent calls on one replica are legal --
+// like the reference's `&self` search (SURVEY.md 8b "Threading").
 class DeviceIndex {
 public:
-    DeviceIndex() = default;
+    DeviceIndex();
     ~DeviceIndex();
     DeviceIndex(const DeviceIndex&) = delete;
     DeviceIndex& operator=(const DeviceIndex&) = delete;
@@ -40,67 +56,64 @@ public:
     uint64_t bytes() const { return bytes_; }
 
     // Hnsw::parallel_search on device-resident buffers.  d_queries: nq x d row-major.
+    // d_allowed != nullptr: Hnsw::search_filter with the sorted id vector d_allowed[0..n_allowed) (device memory) for
+    // every query of the batch (src/hnsw.rs:1487-1580, src/filter.rs:11-15).
     int search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                       float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
-                      uint32_t* d_stats, void* stream, std::string& err);
-    // same with host buffers (H2D + kernel + D2H)
+                      uint32_t* d_stats, void* stream, const uint64_t* d_allowed, uint64_t n_allowed, CallInfo* info,
+                      std::string& err);
+    // same with host buffers (H2D + kernels + D2H); out_status (may be null): per query, 1 = the reference panics
     int search_host(const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids,
-                    float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts, std::string& err);
+                    float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
+                    const uint64_t* allowed, uint64_t n_allowed, bool filtered, uint8_t* out_status, CallInfo* info,
+                    std::string& err);
 
-    // strict ties: re-run tie-affected queries with a literal emulation of the reference's binary heaps
-    void set_strict_ties(bool on) { strict_ties_ = on; }
-    bool strict_ties() const { return strict_ties_; }
-    uint32_t last_ties() const { return last_ties_; }
-    double last_kernel_ms() const { return last_ms_; }
-    double last_main_kernel_ms() const { return last_main_ms_; }
-    uint32_t last_launches() const { return last_launches_; }
+    // strict ties: decisions that depend on the reference's heap order are resolved with literal heaps
+    void set_strict_ties(bool on) { strict_ties_.store(on); }
+    bool strict_ties() const { return strict_ties_.load(); }
+    CallInfo last_call() const;
 
 private:
-    int ensure_workspace(uint64_t nq, uint64_t k, std::string& err);
+    struct Workspace;
+    class Lease;
+    Workspace* acquire(std::string& err);
+    void release_ws(Workspace* w);
     void release();
+    int run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_qlist, uint32_t nq, uint64_t k, uint64_t ef,
+                  const uint32_t* d_allow, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
+                  int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* stats, void* stream, uint32_t* panics,
+                  std::string& err);
+
     DeviceIndexView v_{};
     bool ready_ = false;
     int device_ = -1;
     int dist_ = DIST_L2;
     int num_cu_ = 0;
     uint64_t bytes_ = 0;
-    // device allocations owned by this object
+    // the replica (read-only after upload)
     void* d_vec_ = nullptr;
     void* d_nbr0_ = nullptr;
     void* d_up_ptr_ = nullptr;
     void* d_up_ids_ = nullptr;
     void* d_origin_ = nullptr;
-    void* d_nrm2_ = nullptr;      // HNSW_COSINE_GROUPS builds: per-point squared norms (f64)
-    // per-call workspace (grown on demand)
-    void* d_qpad_ = nullptr;      uint64_t qpad_cap_ = 0;     // padded queries
-    void* d_ctrl_ = nullptr;                                   // work counter, overflow counter
-    void* h_ctrl_ = nullptr;                                   // pinned host copy of the counters (read back once per launch)
-    void* d_retry_[2] = {nullptr, nullptr}; uint64_t retry_cap_ = 0;
-    void* d_stats_ = nullptr;     uint64_t stats_cap_ = 0;
-    void* d_bitmap_ = nullptr;    uint64_t bitmap_cap_ = 0;
-    void* d_hostio_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // for search_host
-    uint64_t hostio_cap_q_ = 0, hostio_cap_k_ = 0, hostio_cap_n_ = 0;
-    void* ev_start_ = nullptr;
-    void* ev_stop_ = nullptr;
-    void* ev_mid_ = nullptr;
-    void* d_tie_ = nullptr;       uint64_t tie_cap_ = 0;      // queries flagged with an exact distance tie
-    void* d_predist_ = nullptr;   void* d_order_ = nullptr;   // batch scheduling (estimate pass)
-    uint64_t sched_cap_ = 0;
-    void* ev_ks_ = nullptr;       void* ev_ke_ = nullptr;     // around the first launch of the search kernel
-    void* d_heaps_ = nullptr;     uint64_t heaps_cap_ = 0;    // scratch of the exact replay
-    void* d_cand_ = nullptr;      uint64_t strict_cap_ = 0;   // in-launch literal heaps: candidate_points beyond LDS
-    uint64_t adapt_exact_ef_ = 0; bool adapt_exact_first_ = false;  // previous batch: did most queries meet a tie?
-    bool strict_ties_ = true;
-    uint32_t last_ties_ = 0;
-    uint64_t adapt_ef_ = 0;       // visited-table sizing learned from previous batches with this ef
+    void* d_nrm2_ = nullptr;      // DistCosine: per-point squared norms (f64)
+    // per-call workspaces
+    std::mutex pool_mu_;
+    std::vector<std::unique_ptr<Workspace>> all_ws_;
+    std::vector<Workspace*> free_ws_;
+    // what previous batches taught us (visited-table sizing per ef), and the last call's report
+    mutable std::mutex meta_mu_;
+    uint64_t adapt_ef_ = 0;
     uint32_t adapt_tbits_ = 0;
-    double last_ms_ = 0.0;
-    double last_main_ms_ = 0.0;
-    uint32_t last_launches_ = 0;
+    CallInfo last_{};
+    std::atomic<bool> strict_ties_{true};
 };
 
 int device_count();
-// Distance<f32>::eval on the device for n pairs, same arithmetic as the search kernel.
-int eval_distances_device(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out, std::string& err);
+// Distance<f32>::eval on the device through the search kernel's own distance routine: out[q][r] = dist(queries[q],
+// rows[r]), rows evaluated in batches of `nf` (1..64) -- the lane-group branches the search takes for nf neighbours.
+// pairs: nq == n and out[i] = dist(queries[i], rows[i]) (nf ignored).
+int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
+                                uint32_t nf, bool pairs, float* out, std::string& err);
 
 }  // namespace hnswgpu

@@ -7,29 +7,25 @@
 
 namespace hnswgpu {
 
-constexpr uint32_t EXPANDED = 0x80000000u;  // flag bit on a result entry whose neighbour list was read
+constexpr uint32_t EXPANDED = 0x80000000u;  // flag bit on a result entry whose neighbour list was read (=> n < 2^31)
 constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
 // visited-set representations (see visit_*)
 constexpr int TABLE_LDS_CELL16 = 0;
 constexpr int TABLE_LDS_CELL32 = 1;
 constexpr int TABLE_GLOBAL_BITMAP = 2;
 
-// LDS carve (bytes) in front of the visited table
-constexpr uint32_t TILE_ROWS = 16;                       // rows transposed per sub-batch
-constexpr uint32_t TILE_PITCH = TILE_ROWS + 1;           // float4 units; +1 keeps ds_write_b128 conflict-free
-constexpr uint32_t TILE_BYTES = 2 * 8 * TILE_PITCH * 16; // two buffers of 8 chunks x 16 B per row and pass
-constexpr uint32_t IDS_BYTES = 64 * 4;
+constexpr uint32_t IDS_BYTES = 64 * 4;  // LDS: the compacted ids of one batch of neighbours
 
 typedef unsigned long long hent_t;  // heap / log entry: {key f32 (high), id u32 (low)}
 
 struct SearchArgs {
     const float* queries;   // [nq][row_stride], zero padded
-    const uint32_t* qlist;  // optional: indices of the queries to run (retry pass), else nullptr
+    const uint32_t* qlist;  // optional: indices of the queries to run (scheduling order / retry pass), else nullptr
     uint32_t nq;            // number of work items
     uint32_t k;
     uint32_t ef;            // already max(ef_arg, k)
     uint32_t tbits;         // visited table = 1 << tbits cells
-    uint32_t tile_bytes;    // LDS bytes in front of the id buffer: transposing tile (cosine) or the staged query row
+    uint32_t tile_bytes;    // LDS bytes in front of the id buffer: the staged query row (+ its squared norm for DistCosine)
     uint32_t idbits;        // ceil(log2(n))
     uint32_t restbits;      // CELL16: idbits - tbits bits of the mixed id kept in the cell
     uint32_t* work_counter; // persistent-grid work queue head
@@ -38,61 +34,61 @@ struct SearchArgs {
     uint32_t* bitmap;       // [bitmap_blocks][bitmap_words]: per-workgroup visited bitmaps in HBM
     uint32_t bitmap_words;
     uint32_t bitmap_blocks; // workgroups with blockIdx.x < bitmap_blocks own a slice
-    uint32_t* tie_list;     // strict ties: queries that met an exact distance tie (count at overflow_count + 3)
-    hent_t* cand_scratch;   // strict ties: [gridDim.x][cand_cap] candidate heap beyond its LDS part
+    uint32_t* tie_list;     // queries whose answer depends on the reference's heap order and was not resolved in the launch
+                            // (count at overflow_count + 3)
+    hent_t* cand_scratch;   // strict ties: [gridDim.x][cand_cap] literal candidate heap beyond its LDS part
     uint32_t cand_cap;
-    uint32_t cand_lds;      // strict ties: entries of candidate_points kept in LDS (behind the visited table)
-    uint32_t exact_first;   // strict ties: skip the sorted-array attempt, answer every query with the literal heaps
-#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
-    const double* nrm2;     // experiment: [n] squared norm of every point, f64 left-to-right sum of f32 squares (= DistCosine's third sum)
-#endif
-#if (defined(HNSW_STRICT_RESUME) && HNSW_STRICT_RESUME) || (defined(HNSW_EXACT_VALUE_R) && HNSW_EXACT_VALUE_R)
-    hent_t* oplog;          // experiment: [gridDim.x][oplog_cap] per-workgroup log of the first attempt's heap operations
+    uint32_t cand_lds;      // strict ties: entries of the literal candidate heap kept in LDS (behind the visited table)
+    uint32_t exact_first;   // strict ties, test hook: literal candidate heap from the first pop on
+    hent_t* oplog;          // strict ties: [gridDim.x][oplog_cap] per-workgroup log of heap operations
     uint32_t oplog_cap;
-#endif
+    const double* nrm2;     // DistCosine: [n] squared norm of every point (f64 left-to-right sum of f32 squares)
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
     int32_t* out_rank;
     uint32_t* out_counts;
     float* pre_dist;        // hnsw_estimate_kernel: [nq] estimated distance to the layer-0 entry point (scheduling key)
-    uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used, 0
+    uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used, flags
 };
 
 struct ExactArgs {
-    hent_t* heaps;        // [gridDim.x][heap_stride]: return_points (ef + 2 entries) then candidate_points
-    uint64_t heap_stride; // entries per workgroup
-    uint32_t cand_cap;    // capacity of candidate_points
-    uint32_t r_lds_cap;   // entries of return_points kept in LDS
-    uint32_t cand_lds;    // entries of candidate_points kept in LDS
+    hent_t* heaps;          // [gridDim.x][heap_stride]: return_points (ef + 2 entries) then candidate_points
+    uint64_t heap_stride;   // entries per workgroup
+    uint32_t cand_cap;      // capacity of candidate_points
+    uint32_t r_lds_cap;     // entries of return_points kept in LDS
+    uint32_t cand_lds;      // entries of candidate_points kept in LDS
+    const uint32_t* allow;  // filtered search: one bit per flat id (nullptr = Hnsw::search, no filter)
 };
 
 // One translation unit per metric instantiates the kernels (keeps the build parallel and the objects small).
 struct KernelSet {
-    // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (queries that meet an
-    // exact f32 tie are searched again with literal heaps inside the launch) or lean
+    // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (decisions that depend on the
+    // reference's heap order are resolved with literal heaps inside the launch) or lean (such queries are only flagged)
     hipError_t (*launch_search)(int slots, int table, bool strict, uint32_t grid, size_t lds, hipStream_t stream,
                                 const DeviceIndexView& ix, const SearchArgs& a);
     hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);
     hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
                                const SearchArgs& a, const ExactArgs& x);
-    hipError_t (*launch_eval_pairs)(uint32_t blocks, const float* a, const float* b, float* out, uint32_t n, uint32_t row_stride);
     // batch scheduling: estimated distance of every query to its layer-0 entry point, then the queries in descending
     // order of it
     hipError_t (*launch_estimate)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const SearchArgs& a);
     hipError_t (*launch_order)(hipStream_t stream, const float* keys, uint32_t n, uint32_t* order);
+    // arithmetic tests: out[q][r] = dist(queries[q], rows[r]) through batch_dist, rows in batches of nf; or, pairs:
+    // out[q] = dist(queries[q], rows[q])
+    hipError_t (*launch_eval_matrix)(hipStream_t stream, const float* queries, uint32_t nq, const float* rows, uint32_t n_rows,
+                                     const double* nrm2, float* out, uint32_t row_stride, uint32_t nf, bool pairs);
 };
-// LDS in front of the id buffer: cosine transposes row tiles through it, the other metrics keep the query there
+// LDS in front of the id buffer: the query row; DistCosine keeps the query's squared norm (f64) behind it
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
-#if defined(HNSW_COSINE_GROUPS) && HNSW_COSINE_GROUPS
-    return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE ? 16u : 0u);  // + the query's squared norm (f64)
-#else
-    return metric == DIST_COSINE ? TILE_BYTES : ((row_stride * 4u + 15u) & ~15u);
-#endif
+    return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE ? 16u : 0u);
 }
 const KernelSet& kernels_l2();
 const KernelSet& kernels_cosine();
 const KernelSet& kernels_dot();
 const KernelSet& kernels_l1();
+// metric-independent helpers (instantiated once, in the L2 translation unit)
+hipError_t launch_allow_bitmap(hipStream_t stream, const uint64_t* origin_id, uint32_t n, const uint64_t* ids, uint64_t m, uint32_t* allow);
+hipError_t launch_row_sq_norms(hipStream_t stream, const float* vec, double* out, uint32_t n, uint32_t row_stride);
 
 }  // namespace hnswgpu

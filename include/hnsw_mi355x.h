@@ -39,7 +39,9 @@ enum {
     HNSWGPU_ERR_DISTANCE = 4, /* dump's distance name differs from the one asked          */
     HNSWGPU_ERR_TYPE = 5,     /* dump's element type is not "f32"                         */
     HNSWGPU_ERR_DEVICE = 6,   /* HIP error, or no gfx950 device / index not uploaded      */
-    HNSWGPU_ERR_EMPTY = 7     /* operation needs a non-empty index                        */
+    HNSWGPU_ERR_EMPTY = 7,    /* operation needs a non-empty index                        */
+    HNSWGPU_ERR_REF_PANIC = 8 /* filtered search: the reference panics on some of the queries
+                                 (src/hnsw.rs:973) and no per-query status array was given  */
 };
 
 /* metric selector == short type name of the anndists distance */
@@ -101,6 +103,13 @@ typedef struct {
 } hnswgpu_build_params;
 int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids /* NULL: 0..n-1 */,
                   const hnswgpu_build_params* params, hnswgpu_index** out);
+/* Hnsw::insert / parallel_insert of n more points into ANY index (src/hnsw.rs:1068-1075, :1224-1238), including one
+ * obtained from hnswgpu_load_dump: like the reference's reloaded Hnsw it keeps growing (M, ef_construction and the
+ * level scale come from the dump; extend_candidates = true, keep_pruned = false as src/hnswio.rs:510-511 sets them;
+ * the reference's reload quirk of treating the dumped absolute level scale as a factor, src/hnswio.rs:773-777, is
+ * kept).  nthreads: 1 = serial, 0 = all host cores.  HBM replicas are refreshed by the next search / upload.           */
+int hnswgpu_insert(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids /* NULL: continue */,
+                   int nthreads);
 
 /* ---------------------------------------------------------------- inspection --------- */
 uint64_t hnswgpu_nb_point(const hnswgpu_index* idx);
@@ -117,7 +126,9 @@ int64_t hnswgpu_neighbours(const hnswgpu_index* idx, unsigned layer, int32_t ran
 
 /* ---------------------------------------------------------------- HBM replica -------- */
 /* Copies vectors (rows padded to 128-byte lines) and neighbour lists into the HBM of HIP
- * device `device` (one process per GPU: call once per process).  Idempotent.              */
+ * device `device`.  Idempotent.  A handle may hold replicas on several devices (one upload
+ * each); the last device uploaded explicitly is the PRIMARY one, used by the single-device
+ * search entry points.  Replicas are immutable; they are dropped when the graph changes.    */
 int hnswgpu_upload(hnswgpu_index* idx, int device);
 int hnswgpu_device_count(void);
 
@@ -130,24 +141,58 @@ int hnswgpu_search_batch(const hnswgpu_index* idx, const float* queries, uint64_
                          uint64_t ef, uint64_t* out_ids, float* out_dists, uint8_t* out_layer, int32_t* out_rank,
                          uint32_t* out_counts);
 
+/* Hnsw::search_filter(data, knbn, ef, Some(&Vec<usize>)) for every query of a batch (src/hnsw.rs:1487-1580; the filter
+ * is `impl FilterT for Vec<usize>`, a binary search in a SORTED id vector, src/filter.rs:11-15 -- an unsorted vector is
+ * HNSWGPU_ERR_ARG).  Same outputs as hnswgpu_search_batch.  The reference panics on some inputs (a filter that empties
+ * return_points, then `peek().unwrap()`, src/hnsw.rs:973 -- only reachable with ef == 1): such a query gets count 0
+ * and out_status[i] = 1 (0 otherwise); with out_status == NULL the call returns HNSWGPU_ERR_REF_PANIC instead (the other
+ * queries' answers are valid).  Never aborts.                                                                      */
+int hnswgpu_search_batch_filtered(const hnswgpu_index* idx, const float* queries, uint64_t nq, uint64_t d, uint64_t k,
+                                  uint64_t ef, const uint64_t* allowed_ids, uint64_t n_allowed, uint64_t* out_ids,
+                                  float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
+                                  uint8_t* out_status);
+
+/* Hnsw::parallel_search with the batch sharded over several GPUs of THIS process (BASELINE config 4 without Python or
+ * a collective library): the graph is replicated on every device named in devices[0..n_shards) (uploaded on first use),
+ * shard s = the s-th contiguous balanced block of queries (nq / n_shards each, the first nq % n_shards one more), one
+ * host thread per shard, and every shard copies its answers straight into its rows of the caller's arrays -- that is
+ * the gather.  A device may be named more than once (shards then share its replica and run concurrently).
+ * Answers are identical to hnswgpu_search_batch on one device.                                                      */
+int hnswgpu_search_batch_sharded(const hnswgpu_index* idx, const int* devices, int n_shards, const float* queries,
+                                 uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dists,
+                                 uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts);
+
 /* Same with every buffer already resident in HBM (device pointers), launched on HIP stream
  * `stream` (hipStream_t as void*; NULL = default stream).  Synchronises `stream` once
  * before returning (the visited-set overflow check needs one 4-byte read-back).
  * d_stats may be NULL, else uint32[nq*8] per query = {n_dist, n_expand, n_ids_read, status,
  * t_start, t_end (device wall clock, 10 ns ticks), used_hbm_bitmap, 0}.
- * status: 0 ok; 2 ok, but an exact f32 distance tie was met and strict ties are off; 3 ok, answered
- * by the literal heaps (strict ties; see DESIGN.md "ties").                                       */
+ * status: 0 ok; 2 ok, but the answer depends on the reference's heap order and strict ties are off;
+ * 3 ok, resolved with the literal heaps (strict ties; see DESIGN.md "ties").  ef above 1024 (the
+ * register-resident result set) is served by the literal-heap kernel: correct, slower.          */
 int hnswgpu_search_batch_device(const hnswgpu_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
                                 uint64_t k, uint64_t ef, uint64_t* d_out_ids, float* d_out_dists,
                                 uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
                                 uint32_t* d_stats, void* stream);
+/* hnswgpu_search_batch_filtered on device-resident buffers (the sorted id vector too).  d_stats[q*8+3] == 6 marks a
+ * query on which the reference panics; *n_panics (may be NULL) counts them.                                        */
+int hnswgpu_search_batch_filtered_device(const hnswgpu_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                                         uint64_t k, uint64_t ef, const uint64_t* d_allowed_ids, uint64_t n_allowed,
+                                         uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
+                                         int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* d_stats, void* stream,
+                                         uint32_t* n_panics);
+/* Concurrency: the search entry points may be called from several host threads on ONE handle at the same time (the
+ * reference's search is `&self`); every call takes a private workspace.  Calls that change the index (insert, upload)
+ * wait for running searches.                                                                                       */
 
-/* Ties.  Two EQUAL f32 distances make the reference's answer depend on the internal order of Rust's
- * BinaryHeap.  The fast kernel orders equals by arrival and flags such queries (stats status 2);
- * with strict ties ON (default; env HNSWGPU_STRICT_TIES=0 or this call turns it off) such a query is
- * searched again, inside the same launch, with a literal emulation of both heaps (stats status 3), so
- * that ids match the reference bit for bit also under ties.  hnswgpu_last_tie_count: queries of the
- * last call that met a tie (flagged, or answered by the literal heaps).                              */
+/* Ties.  Two EQUAL f32 distances can make the reference's answer depend on the internal order of Rust's BinaryHeap.
+ * The kernel follows the reference by VALUE and detects the places where values do not decide (two equal nearest
+ * candidates at a pop, an equal candidate evicted from the result set that is still the farthest distance, equal
+ * distances or an ambiguous survivor among the first k answers).  With strict ties ON (default; env
+ * HNSWGPU_STRICT_TIES=0 or this call turns it off) such a query carries on, inside the same launch, with a literal
+ * emulation of the heap in question rebuilt from a log of the search so far (stats status 3), so that ids match the
+ * reference bit for bit also under ties.  OFF: equals are ordered by arrival and the query is flagged (status 2).
+ * hnswgpu_last_tie_count: queries of the last call that met such a place (resolved, or flagged).                   */
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on);
 int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
 
@@ -157,9 +202,15 @@ int hnswgpu_last_kernel_ms(const hnswgpu_index* idx, double* ms, uint32_t* launc
 /* Same, but only up to the end of the search kernel proper (excludes the exact replay of tied queries). */
 int hnswgpu_last_search_kernel_ms(const hnswgpu_index* idx, double* ms);
 
-/* Distance<f32>::eval evaluated ON THE DEVICE for n pairs (a[i], b[i]) of dimension d, in
- * the same arithmetic as the search kernel (host buffers).  For arithmetic parity tests.  */
+/* Distance<f32>::eval evaluated ON THE DEVICE by the search kernel's own distance routine (batch_dist: lane groups of
+ * 4 or 2 lanes per row, left-to-right sum in the group's first lane) -- for arithmetic parity tests (host buffers).
+ *   hnswgpu_eval_distances:       out[i]    = dist(a[i], b[i]), n pairs (each one a batch of a single row)
+ *   hnswgpu_eval_distance_matrix: out[q][r] = dist(queries[q], rows[r]); the rows are evaluated in batches of `batch`
+ *                                 (1..64) consecutive rows, the branch structure the search takes for that many fresh
+ *                                 neighbours (<= 16 rows: 4 lanes per row; more: 32 rows at 2 lanes per row, ...).  */
 int hnswgpu_eval_distances(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out);
+int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
+                                 uint32_t batch, float* out);
 
 /* =======================================================================================
  * (2) The reference's own C ABI for f32 (src/libext.rs), same names and struct layouts.

@@ -151,6 +151,11 @@ inline std::unique_ptr<Hnsw> load_hnsw(const std::string& dir, const std::string
     auto h = std::unique_ptr<Hnsw>(new Hnsw(descr.max_nb_connection, descr.nb_point, descr.nb_layer, descr.ef, asked));
     h->extend_candidates = true;  // :510
     h->keep_pruned = false;
+    // load_point_indexation builds LayerGenerator::new_with_scale(M, descr.level_scale, NB_LAYER_MAX) (:773-777): the
+    // dumped ABSOLUTE scale is used as a FACTOR of 1/ln(M) (src/hnsw.rs:339-352) -- a quirk, restated as it is: points
+    // inserted after a reload draw their levels with scale = level_scale / ln(M).
+    h->layer_g = LayerGenerator(descr.max_nb_connection, descr.level_scale, NB_LAYER_MAX);
+    h->level_scale_factor = descr.level_scale;
     h->data_dimension = descr.dimension;
     uint8_t nb_layer = get<uint8_t>(g);
     if (nb_layer > NB_LAYER_MAX) throw std::runtime_error("inconsistent number of layErrers");

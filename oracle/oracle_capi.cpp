@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include "hnsw_oracle.hpp"
+#include "flat_baseline.hpp"
 #include "hnswio_oracle.hpp"
 
 using namespace oracle;
@@ -120,6 +121,25 @@ int orc_search_filter(void* hv, const float* q, size_t d, size_t k, size_t ef, c
     return 0;
     ORC_CATCH(-1)
 }
+// The optimised flat-array CPU baseline (flat_baseline.hpp; timing only, never a parity check): built from a loaded index.
+void* orc_flat_new(void* hv) {
+    ORC_TRY
+    return new FlatBaseline(*static_cast<Hnsw*>(hv));
+    ORC_CATCH(nullptr)
+}
+void orc_flat_free(void* fv) { delete static_cast<FlatBaseline*>(fv); }
+int orc_flat_parallel_search(void* fv, const float* queries, size_t nq, size_t d, size_t k, size_t ef, int nthreads,
+                             uint64_t* out_ids, float* out_dists, uint32_t* out_counts, double* elapsed_s) {
+    ORC_TRY
+    FlatBaseline* f = static_cast<FlatBaseline*>(fv);
+    if (d != f->d) throw std::runtime_error("flat baseline: dimension mismatch");
+    auto t0 = std::chrono::steady_clock::now();
+    f->parallel_search(queries, nq, k, ef, nthreads, out_ids, out_dists, out_counts);
+    auto t1 = std::chrono::steady_clock::now();
+    if (elapsed_s) *elapsed_s = std::chrono::duration<double>(t1 - t0).count();
+    return 0;
+    ORC_CATCH(-1)
+}
 // timing-only switch: distances in the crate's SIMD summation order (see dist_simd8); never used by a parity check
 int orc_set_simd_order(void* hv, int on) {
     ORC_TRY
@@ -146,6 +166,11 @@ float orc_dist(int kind, const float* a, const float* b, size_t d) {
     ORC_TRY
     return dist_eval((DistKind)kind, a, b, d);
     ORC_CATCH(NAN)
+}
+// out[q][r] = eval(queries[q], rows[r]) (row-major matrices of dimension d), for the device's distance-routine sweep
+void orc_dist_matrix(int kind, const float* queries, size_t nq, const float* rows, size_t n, size_t d, float* out) {
+    for (size_t q = 0; q < nq; ++q)
+        for (size_t r = 0; r < n; ++r) out[q * n + r] = dist_eval((DistKind)kind, queries + q * d, rows + r * d, d);
 }
 void orc_l2_normalize(float* v, size_t d) { l2_normalize(v, d); }
 

@@ -40,3 +40,20 @@ def normalized(n, d, seed):
     for i in range(n):  # the crate's l2_normalize, f32
         oracle_lib.lib().orc_l2_normalize(x[i].ctypes.data, d)
     return x
+
+
+def same_dump_after_reload(before_graph, after_graph, reloads=1):
+    """A dump written by an index that was RELOADED from `before` equals `before` byte for byte except for the level
+    scale (8 bytes at offset 6 of a v4 graph file): the reference reloads the dumped absolute scale as a factor of
+    1/ln(M) (src/hnswio.rs:773-777, src/hnsw.rs:339-352) and dumps the product again (src/hnswio.rs:1365-1371)."""
+    import math
+    import struct
+    a, b = open(before_graph, "rb").read(), open(after_graph, "rb").read()
+    if len(a) != len(b) or a[:6] != b[:6] or a[14:] != b[14:]:
+        return False
+    m = a[5]
+    sa, sb = struct.unpack("=d", a[6:14])[0], struct.unpack("=d", b[6:14])[0]
+    want = sa
+    for _ in range(reloads):
+        want = want / math.log(float(max(2, m)))
+    return sb == want

@@ -4,6 +4,8 @@
 //   test_sparse_search                          src/hnsw.rs:1870-1881      (gpu mode)
 //   self retrieval, serial == parallel          tests/equality.rs:83-160, src/hnsw.rs:1601-1620   (gpu mode)
 // usage: test_hnsw_rs <cpu|gpu> <tmpdir>
+#include <cmath>
+#include <cstring>
 #include <cassert>
 #include <cstdio>
 #include <cstring>
@@ -41,7 +43,17 @@ int main(int argc, char** argv) {
     REQUIRE(loaded.get_nb_point() == nb_elem);
     REQUIRE(loaded.get_max_level_observed() == hnsw.get_max_level_observed());
     loaded.file_dump(dir, "dumpreloadtest2");
-    REQUIRE(slurp(dir + "/dumpreloadtest.hnsw.graph") == slurp(dir + "/dumpreloadtest2.hnsw.graph"));  // check_graph_equality
+    {   // check_graph_equality: every byte but the level scale (offset 6, f64), which a RELOADED index dumps divided
+        // by ln(M) -- the reference's reload rule (src/hnswio.rs:773-777)
+        std::vector<char> g1 = slurp(dir + "/dumpreloadtest.hnsw.graph"), g2 = slurp(dir + "/dumpreloadtest2.hnsw.graph");
+        REQUIRE(g1.size() == g2.size() && g1.size() > 14);
+        double s1, s2;
+        std::memcpy(&s1, g1.data() + 6, 8);
+        std::memcpy(&s2, g2.data() + 6, 8);
+        REQUIRE(s2 == s1 / std::log(10.0));
+        std::memcpy(&g2[6], g1.data() + 6, 8);
+        REQUIRE(g1 == g2);
+    }
     REQUIRE(slurp(dir + "/dumpreloadtest.hnsw.data") == slurp(dir + "/dumpreloadtest2.hnsw.data"));
     // a dump written for DistL1 cannot be reloaded as DistL2 (src/hnswio.rs:473-490)
     bool refused = false;

@@ -4,7 +4,11 @@
 The reference (Rust) cannot be built or imported in this environment and its tests hold no known-answer
 vectors, so these fixtures pin the ORACLE's outputs (and, through it, the product's) across changes:
   <name>.hnsw.graph / .hnsw.data : an index built by the oracle's restated serial insert, in hnswio format
-  <name>.npz                     : seeded queries + the oracle's answers (ids, f32 distance bits, p_ids, counts)
+  <name>.npz                     : seeded queries + the oracle's answers (ids, f32 distance bits, p_ids, counts), plus a
+                                   sorted-id filter and the oracle's search_filter answers (f_* arrays; count
+                                   0xFFFFFFFF = the reference panics on that query, src/hnsw.rs:973)
+  <name>.queries.bin / .filter.bin : the same queries / filter as raw little-endian files for oracle/ref_pin (the Rust
+                                   program that answers them with the REAL reference: see oracle/PIN.md)
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import os
@@ -39,8 +43,34 @@ def main():
         o.insert_batch(X, ids=np.arange(n) * 3 + 1)
         o.file_dump(HERE, name)
         r = o.parallel_search(Q, k, ef, 1)
+        # filtered search (impl FilterT for Vec<usize>): every third origin id of a contiguous stretch, plus a few ids
+        # that are not in the index
+        origin = np.arange(n, dtype=np.uint64) * 3 + 1
+        allowed = np.sort(np.concatenate([origin[n // 4:n // 2:3], np.array([0, 2, 5, 3 * n + 7], np.uint64)]))
+        f_ids = np.zeros((nq, k), np.uint64)
+        f_bits = np.zeros((nq, k), np.uint32)
+        f_layers = np.zeros((nq, k), np.uint8)
+        f_ranks = np.zeros((nq, k), np.int32)
+        f_counts = np.zeros(nq, np.uint32)
+        for i in range(nq):
+            try:
+                ids, dd, ll, rr = o.search_filter(Q[i], k, ef, allowed)
+            except RuntimeError as e:
+                assert "panics" in str(e), e
+                f_counts[i] = 0xFFFFFFFF
+                continue
+            c = len(ids)
+            f_counts[i] = c
+            f_ids[i, :c], f_bits[i, :c], f_layers[i, :c], f_ranks[i, :c] = ids, dd.view(np.uint32), ll, rr
         np.savez_compressed(os.path.join(HERE, name + ".npz"), queries=Q, k=k, ef=ef, dist=dist, ids=r.ids,
-                            dist_bits=r.dists.view(np.uint32), layers=r.layers, ranks=r.ranks, counts=r.counts)
+                            dist_bits=r.dists.view(np.uint32), layers=r.layers, ranks=r.ranks, counts=r.counts,
+                            filter_ids=allowed, f_ids=f_ids, f_dist_bits=f_bits, f_layers=f_layers, f_ranks=f_ranks,
+                            f_counts=f_counts)
+        with open(os.path.join(HERE, name + ".queries.bin"), "wb") as f:
+            f.write(np.array([nq, d, k, ef], "<u4").tobytes())
+            f.write(Q.astype("<f4").tobytes())
+        with open(os.path.join(HERE, name + ".filter.bin"), "wb") as f:
+            f.write(allowed.astype("<u8").tobytes())
         print(name, "points", n, "queries", nq, "graph bytes", os.path.getsize(os.path.join(HERE, name + ".hnsw.graph")))
 
 

@@ -18,7 +18,7 @@ DIST_BY_NAME = {"DistL2": DIST_L2, "DistCosine": DIST_COSINE, "DistDot": DIST_DO
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "hnsw_oracle.hpp", "hnswio_oracle.hpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "hnsw_oracle.hpp", "hnswio_oracle.hpp", "flat_baseline.hpp")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
@@ -60,6 +60,12 @@ def lib():
         L.orc_dist.restype = C.c_float
         L.orc_dist.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_l2_normalize.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_flat_new.restype = C.c_void_p
+        L.orc_flat_new.argtypes = [C.c_void_p]
+        L.orc_flat_free.argtypes = [C.c_void_p]
+        L.orc_flat_parallel_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_dist_matrix.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_levels.argtypes = [C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_heap_exercise.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                         C.c_void_p]
@@ -181,6 +187,10 @@ class OracleHnsw:
         c = cnt.value
         return ids[:c], dists[:c], layers[:c], ranks[:c]
 
+    def flat_baseline(self):
+        """The optimised flat-array CPU searcher built from this index (timing only: see oracle/flat_baseline.hpp)."""
+        return FlatBaseline(self)
+
     def set_simd_order(self, on):
         """Timing-only: distances summed in the crate's SIMD (8-lane) order; results differ in the last bits."""
         lib().orc_set_simd_order(C.c_void_p(self.h), int(bool(on)))
@@ -198,10 +208,44 @@ class OracleHnsw:
         return OracleHnsw(dist=dist, _handle=h)
 
 
+class FlatBaseline:
+    def __init__(self, orc):
+        self.f = lib().orc_flat_new(C.c_void_p(orc.h))
+        if not self.f:
+            raise RuntimeError(_err())
+
+    def __del__(self):
+        if getattr(self, "f", None):
+            lib().orc_flat_free(C.c_void_p(self.f))
+            self.f = None
+
+    def parallel_search(self, queries, k, ef, nthreads=0):
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, d = queries.shape
+        ids = np.zeros((nq, k), np.uint64)
+        dists = np.zeros((nq, k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        elapsed = C.c_double(0.0)
+        if lib().orc_flat_parallel_search(C.c_void_p(self.f), _p(queries), nq, d, k, ef, nthreads, _p(ids), _p(dists), _p(counts),
+                                          C.byref(elapsed)) != 0:
+            raise RuntimeError(_err())
+        res = SearchResult(ids, dists, None, None, counts)
+        res.elapsed_s = elapsed.value
+        return res
+
+
 def dist_eval(kind, a, b):
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)
     return float(lib().orc_dist(DIST_BY_NAME[kind], _p(a), _p(b), a.shape[0]))
+
+
+def dist_matrix(kind, queries, rows):
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    r = np.ascontiguousarray(rows, dtype=np.float32)
+    out = np.zeros((q.shape[0], r.shape[0]), np.float32)
+    lib().orc_dist_matrix(DIST_BY_NAME[kind], _p(q), q.shape[0], _p(r), r.shape[0], q.shape[1], _p(out))
+    return out
 
 
 def levels(max_nb_conn, n, scale_factor=1.0, maxlevel=16):

@@ -24,11 +24,13 @@ def test_cpu_baseline_leg_reports_timing_and_parity(oracle, tmp_path):
     assert set(cpu["by_threads"]) == set(cpu["by_threads_simd_order"])
     assert parity["queries_checked"] == nq
     assert parity["tie_free_ids_identical"] and parity["tie_free_f32_distance_bits_identical"]
-    assert parity["queries_with_exact_distance_tie"] == 2 and parity["tied_queries_resolved_with_literal_heaps"] == 1
-    assert parity["tied_queries_ids_identical"] == 2 and parity["tied_queries_distance_bits_identical"] == 2
+    assert parity["all_ids_identical"] and parity["all_f32_distance_bits_identical"]
+    assert parity["queries_whose_answer_depends_on_heap_order"] == 2 and parity["resolved_with_literal_heaps"] == 1
+    assert parity["heap_order_queries_ids_identical"] == 2 and parity["heap_order_queries_distance_bits_identical"] == 2
+    assert cpu["protocol"].startswith("1 warm-up") and cpu["flat_avx"]["value"] > 0 and cpu["flat_avx"]["ids_agreeing_with_the_port"] > 0.98
     # a corrupted device answer must show up
     bad = ref.ids.astype(np.int64).copy()
     bad[0, 0] ^= 1
     _, parity2 = bench.cpu_baseline_leg(str(tmp_path), "leg", "DistL2", Q, k, ef, bad, ref.dists.copy(), st,
                                         ref.counts.astype(np.int32), cpu_seconds=0.2)
-    assert not parity2["tie_free_ids_identical"]
+    assert not parity2["tie_free_ids_identical"] and not parity2["all_ids_identical"]

@@ -97,3 +97,40 @@ def test_bad_parameters(native):
     h = native.Hnsw(8, 10, 16, 20, "DistL2")
     with pytest.raises(native.HnswError):
         h.parallel_insert(np.zeros((3,), np.float32))
+
+
+@pytest.mark.parametrize("dist", ["DistL2", "DistCosine"])
+def test_reloaded_index_keeps_growing_like_the_oracle(native, oracle, tmp_path, dist):
+    """HnswIo::load_hnsw returns a fully insertable Hnsw (its layer generator is rebuilt from the dumped scale,
+    src/hnswio.rs:773-777; extend_candidates = true, keep_pruned = false, :510-511).  The product seeds its builder from the
+    loaded graph: inserting the same points serially into the reloaded index gives the oracle's bytes."""
+    X = uniform(700, 12, 5)
+    first, more = X[:500], X[500:]
+    o = oracle.OracleHnsw(8, 700, 16, 40, dist)
+    o.insert_batch(first)
+    o.file_dump(tmp_path, "half")
+    o2 = oracle.OracleHnsw.load(tmp_path, "half", dist)
+    o2.insert_batch(more, ids=np.arange(500, 700))
+    assert o2.get_nb_point() == 700
+    o2.file_dump(tmp_path, "orc_full")
+    h = native.HnswIo(tmp_path, "half").load_hnsw(dist)
+    h.insert_serial(more, ids=np.arange(500, 700))
+    assert h.get_nb_point() == 700
+    h.file_dump(tmp_path, "prod_full")
+    assert dumps_equal(tmp_path, "orc_full", "prod_full")
+    # the reference-style FFI inserts into a reloaded handle as well (it used to drop the points silently)
+    import ctypes as C
+    lib = native.lib()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        api = lib.load_hnswdump_f32_DistL2(lib.get_hnswio(4, b"half")) if dist == "DistL2" else lib.load_hnswdump_f32_DistCosine(lib.get_hnswio(4, b"half"))
+        assert api
+        for i in range(200):
+            lib.insert_f32(api, 12, more[i].ctypes.data, 500 + i)
+        assert lib.hnswgpu_nb_point(lib.hnswgpu_from_api(api)) == 700
+        assert lib.file_dump_f32(api, 8, b"ffi_full") == 1
+        lib.drop_hnsw_f32(api)
+    finally:
+        os.chdir(cwd)
+    assert dumps_equal(tmp_path, "orc_full", "ffi_full")

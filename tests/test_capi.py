@@ -53,7 +53,9 @@ def test_reference_style_load_dump_description(native, oracle, tmp_path, monkeyp
     idx = lib.hnswgpu_from_api(api)
     assert lib.hnswgpu_nb_point(idx) == 300 and lib.hnswgpu_dimension(idx) == 6
     assert lib.file_dump_f32(api, 4, b"cmp2") == 1
-    assert open("cmp2.hnsw.graph", "rb").read() == open("cmp.hnsw.graph", "rb").read()
+    from conftest import same_dump_after_reload
+    assert same_dump_after_reload("cmp.hnsw.graph", "cmp2.hnsw.graph")
+    assert open("cmp2.hnsw.data", "rb").read() == open("cmp.hnsw.data", "rb").read()
     d = lib.load_hnsw_description(len(b"cmp.hnsw.graph"), b"cmp.hnsw.graph")
     assert d and d.contents.max_nb_connection == 9 and d.contents.ef == 30 and d.contents.data_dimension == 6
     assert d.contents.dumpmode == 1 and d.contents.nb_point == 0  # reference quirks (src/libext.rs:1198-1206)
