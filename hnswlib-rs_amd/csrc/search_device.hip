@@ -475,10 +475,12 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         SearchArgs a{};
         size_t lds = lds_fixed;
         if (table != TABLE_GLOBAL_BITMAP) {
-            uint32_t tb = std::min(tbits, idbits);  // a table with one cell per possible id never probes
-            if (idbits - tb <= 11u) {
+            // buckets of 8 cells: the id's top (tb - 3) bits select the bucket, the cell keeps the other restbits bits
+            // next to a 2-bit bucket displacement and the valid bit (16-bit cells: restbits <= 13)
+            uint32_t tb = std::max(3u, std::min(tbits, idbits + 3u));
+            if (idbits - (tb - 3u) <= 13u) {
                 table = TABLE_LDS_CELL16;
-                a.restbits = idbits - tb;
+                a.restbits = idbits - (tb - 3u);
                 lds += (size_t)2 << tb;
             } else {
                 table = TABLE_LDS_CELL32;

@@ -27,7 +27,7 @@ struct SearchArgs {
     uint32_t tbits;         // visited table = 1 << tbits cells
     uint32_t tile_bytes;    // LDS bytes in front of the id buffer: the staged query row (+ its squared norm for DistCosine)
     uint32_t idbits;        // ceil(log2(n))
-    uint32_t restbits;      // CELL16: idbits - tbits bits of the mixed id kept in the cell
+    uint32_t restbits;      // CELL16: bits of the mixed id kept in the cell = idbits - (tbits - 3) (8-cell buckets)
     uint32_t* work_counter; // persistent-grid work queue head
     uint32_t* overflow_count;
     uint32_t* retry_out;    // queries whose visited table overflowed
