@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--ef", type=int, default=0)
     ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
     ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--host-build", action="store_true", help="build the graph on the host cores only (default: GPU-assisted "
+                    "construction: the insertions' searches on the device, window by window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
     ap.add_argument("--dump-stats", default="", help="write the per-query kernel stats of the last step to this .npy")
@@ -238,26 +240,30 @@ def main():
     lib = H.lib()
 
     # ---------------------------------------------------------------- index (cached hnswio dump)
-    key = hashlib.sha1(json.dumps([args.config, n, d, cfg["dist"], cfg["M"], cfg["efc"], args.data, "v1"]).encode()).hexdigest()[:12]
+    builder = "host" if args.host_build else "gpu"
+    key = hashlib.sha1(json.dumps([args.config, n, d, cfg["dist"], cfg["M"], cfg["efc"], args.data, "v2", builder]).encode()).hexdigest()[:12]
     os.makedirs(args.cache_dir, exist_ok=True)
     base = f"bench_{args.config}_{key}"
     done_marker = os.path.join(args.cache_dir, base + ".done")
     t_build = 0.0
     if rank == 0 and not os.path.exists(done_marker):
-        log(f"building {cfg['label']} ({args.data} data) on the host cores ...")
+        log(f"building {cfg['label']} ({args.data} data), {'host cores only' if args.host_build else 'GPU-assisted'} ...")
         X = synth(n, d, 0x5EED0001, args.data)
         if cfg["dist"] == "DistDot":
             X /= np.linalg.norm(X, axis=1, keepdims=True)
         t0 = time.time()
         hb = H.Hnsw(cfg["M"], n, 16, cfg["efc"], cfg["dist"])
-        hb.set_build_options(nthreads=args.build_threads, fast_arithmetic=True)
+        if args.host_build:
+            hb.set_build_options(nthreads=args.build_threads, fast_arithmetic=True)
+        else:
+            hb.set_build_options(nthreads=args.build_threads, gpu_device=local_rank, gpu_window=0)
         hb.parallel_insert(X)
         t_build = time.time() - t0
         log(f"built in {t_build:.1f} s ({n / t_build:.0f} points/s); dumping to {args.cache_dir}")
         hb.file_dump(args.cache_dir, base)
         del hb, X
         with open(done_marker, "w") as f:
-            f.write(json.dumps({"build_s": t_build}))
+            f.write(json.dumps({"build_s": t_build, "builder": builder}))
     while not os.path.exists(done_marker):  # other ranks: wait on the file system, not on a collective
         time.sleep(1.0)
     t0 = time.time()
@@ -437,7 +443,7 @@ def main():
             "metric": "queries/sec (+ recall@10), batched HNSW search",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": f"synthetic ({args.data}, seeds 0x5EED0001/0x5EED0002), graph built by the product builder",
+            "dtype": "f32", "data": f"synthetic ({args.data}, seeds 0x5EED0001/0x5EED0002), graph built by the product builder ({'host cores' if args.host_build else 'GPU-assisted construction'})",
             "config": {"workload": cfg["label"], "n": n, "d": d, "distance": cfg["dist"], "M": cfg["M"],
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
                        "queries_total": nq_total, "graph": "replicated per GPU", "exchange": "all_gather of answers (RCCL)" if world > 1 else "none"},

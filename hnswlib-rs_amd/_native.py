@@ -58,7 +58,8 @@ class Description(C.Structure):
 class BuildParams(C.Structure):
     _fields_ = [("max_nb_connection", C.c_uint64), ("ef_construction", C.c_uint64), ("max_layer", C.c_uint64),
                 ("dist", C.c_int), ("level_scale_factor", C.c_double), ("extend_candidates", C.c_int),
-                ("keep_pruned", C.c_int), ("nthreads", C.c_int), ("fast_arithmetic", C.c_int)]
+                ("keep_pruned", C.c_int), ("nthreads", C.c_int), ("fast_arithmetic", C.c_int), ("gpu_assist", C.c_int),
+                ("gpu_device", C.c_int), ("gpu_window", C.c_uint64)]
 
 
 class Neighbour_api(C.Structure):  # src/libext.rs:64-71
@@ -91,6 +92,7 @@ SYMBOLS = {
     "hnswgpu_get_description": (_I, [_VP, C.POINTER(Description)]),
     "hnswgpu_build": (_I, [_VP, _U64, _U64, _VP, C.POINTER(BuildParams), C.POINTER(_VP)]),
     "hnswgpu_insert": (_I, [_VP, _VP, _U64, _U64, _VP, _I]),
+    "hnswgpu_insert_gpu": (_I, [_VP, _VP, _U64, _U64, _VP, _I, _I, _U64]),
     "hnswgpu_nb_point": (_U64, [_VP]),
     "hnswgpu_dimension": (_U64, [_VP]),
     "hnswgpu_dist": (_I, [_VP]),

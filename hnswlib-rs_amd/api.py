@@ -70,7 +70,7 @@ class Hnsw:
             if max_nb_connection > 256:
                 # the reference prints and calls process::exit(1) (src/hnsw.rs:784-787); we raise instead
                 raise HnswError(N.ERR_ARG, "error max_nb_connection must be less equal than 256")
-            self._params = N.BuildParams(max_nb_connection, ef_construction, max_layer, N.DIST[dist], 1.0, 0, 0, 0, 0)
+            self._params = N.BuildParams(max_nb_connection, ef_construction, max_layer, N.DIST[dist], 1.0, 0, 0, 0, 0, 0, 0, 0)
             self._dist = dist
         else:
             self._dist = N.DIST_NAME[self._lib.hnswgpu_dist(self._h)]
@@ -90,12 +90,19 @@ class Hnsw:
     def modify_level_scale(self, scale_modification):
         self._params.level_scale_factor = min(1.0, max(0.2, float(scale_modification)))
 
-    def set_build_options(self, nthreads=None, fast_arithmetic=None):
-        """Extension: 1 thread = deterministic serial insert; fast_arithmetic = SIMD-order sums."""
+    def set_build_options(self, nthreads=None, fast_arithmetic=None, gpu_device=None, gpu_window=None):
+        """Extension: 1 thread = deterministic serial insert; fast_arithmetic = SIMD-order sums; gpu_device >= 0 =
+        GPU-assisted construction (the insertions' searches on the device, window by window; gpu_window = 1: one point
+        at a time, the serial insertion exactly)."""
         if nthreads is not None:
             self._params.nthreads = int(nthreads)
         if fast_arithmetic is not None:
             self._params.fast_arithmetic = int(bool(fast_arithmetic))
+        if gpu_device is not None:
+            self._params.gpu_assist = int(gpu_device >= 0)
+            self._params.gpu_device = max(0, int(gpu_device))
+        if gpu_window is not None:
+            self._params.gpu_window = int(gpu_window)
 
     # ---- insertion (host construction; src/hnsw.rs:1069-1238) ---------------------------
     def parallel_insert(self, data, ids=None):
@@ -110,7 +117,12 @@ class Hnsw:
             idp = _p(ids)
         if self._h is not None:
             nthreads = self._params.nthreads if hasattr(self, "_params") else 0
-            _check(self._lib.hnswgpu_insert(self._h, _p(data), data.shape[0], data.shape[1], idp, nthreads))
+            gpu = self._params.gpu_device if hasattr(self, "_params") and self._params.gpu_assist else -1
+            if gpu >= 0:
+                _check(self._lib.hnswgpu_insert_gpu(self._h, _p(data), data.shape[0], data.shape[1], idp, nthreads, gpu,
+                                                    self._params.gpu_window))
+            else:
+                _check(self._lib.hnswgpu_insert(self._h, _p(data), data.shape[0], data.shape[1], idp, nthreads))
             return
         h = C.c_void_p()
         _check(self._lib.hnswgpu_build(_p(data), data.shape[0], data.shape[1], idp, C.byref(self._params),

@@ -422,15 +422,13 @@ void GraphBuilder::insert_one(uint32_t id, Tls& t) {
     }
 }
 
-int GraphBuilder::insert_batch(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
-                               std::string& err) {
-    if (n == 0) return OK;
+// generate_new_point for a whole batch, in input order (src/hnsw.rs:503-531): level, rank, origin id, vector
+int GraphBuilder::append_points(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, std::string& err) {
     if (!data || d == 0) { err = "insert: null data or zero dimension"; return ERR_ARG; }
     if (d_ == 0) d_ = d;
     if (d != d_) { err = "insert: dimension differs from the index dimension"; return ERR_ARG; }
     if (n_ + n >= NO_POINT) { err = "insert: too many points for 32-bit ids"; return ERR_ARG; }
     if (p_.max_nb_connection > 256 || p_.max_nb_connection < 2) { err = "max_nb_connection must be in [2, 256]"; return ERR_ARG; }
-    // generate_new_point for the whole batch, in input order (src/hnsw.rs:503-531)
     const uint64_t first = n_;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t id = (uint32_t)(first + i);
@@ -445,6 +443,15 @@ int GraphBuilder::insert_batch(const float* data, uint64_t n, uint64_t d, const 
         std::memcpy(vecs_[id >> 16].get() + (uint64_t)(id & (CHUNK - 1)) * d_, data + i * d, d * sizeof(float));
     }
     n_ = first + n;
+    return OK;
+}
+
+int GraphBuilder::insert_batch(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
+                               std::string& err) {
+    if (n == 0) return OK;
+    const uint64_t first = n_;
+    int rc = append_points(data, n, d, ids, err);
+    if (rc != OK) return rc;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads < 1) nthreads = 1;
     uint64_t start = first;
@@ -470,6 +477,155 @@ int GraphBuilder::insert_batch(const float* data, uint64_t n, uint64_t d, const 
     for (int k = 1; k < nthreads; ++k) th.emplace_back(worker);
     worker();
     for (auto& x : th) x.join();
+    return OK;
+}
+
+// insert_slice for one point of a window, with the device's search results in place of the host searches
+// (src/hnsw.rs:1106-1213): hits above the point's level, select_neighbours + list per layer, reverse update, entry point.
+void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_entry, unsigned frozen_entry_level, uint32_t layer_mask,
+                                      const WindowSearchResults& r, uint64_t ef_c, Tls& t, std::vector<uint32_t>& dirty) {
+    Node& np = node(id);
+    const float* data = vec(id);
+    const unsigned level = np.level;
+    layer_inserted_[level].fetch_add(1, std::memory_order_acq_rel);  // points_by_layer[level].push (:516)
+    for (int l = (int)frozen_entry_level; l >= (int)level + 1; --l) {  // :1114-1155, searched on the device with ef = 1
+        const uint32_t hid = r.hit_ids[(size_t)wi * NB_LAYER_MAX + (unsigned)l];
+        if (hid == NO_POINT) continue;
+        SpinGuard g(np.lock);
+        std::vector<Edge>& lst = np.list((unsigned)l);
+        if (lst.size() < (size_t)(uint8_t)p_.max_nb_connection) lst.push_back(Edge{hid, r.hit_d[(size_t)wi * NB_LAYER_MAX + (unsigned)l]});  // :1140-1144
+        dirty.push_back((id << 4) | (uint32_t)l);
+    }
+    for (int l = (int)level; l >= 0; --l) {  // :1158-1205
+        t.res.clear();
+        if ((unsigned)l > frozen_entry_level) {
+            // a layer above the snapshot's entry point: search_layer finds the entry point alone, if the layer has a point
+            // at all (this one counts: generate_new_point pushed it before the search, :516)
+            // (the serial reference sees this point in the layer when l is its own level; other empty layers return nothing)
+            if ((unsigned)l == level || ((layer_mask >> l) & 1u)) t.res.push_back(Edge{frozen_entry, eval(data, vec(frozen_entry))});
+        } else {
+            const size_t slot = (size_t)r.slot0[wi] + (size_t)l;
+            const uint32_t cnt = r.out_n[slot];
+            for (uint32_t j = 0; j < cnt; ++j) t.res.push_back(Edge{r.out_ids[slot * ef_c + j], r.out_d[slot * ef_c + j]});
+        }
+        if (!t.res.empty()) {
+            size_t nb_conn = l == 0 ? 2 * p_.max_nb_connection : p_.max_nb_connection;
+            bool extend_c = l == 0 ? p_.extend_candidates : false;
+            select_neighbours(data, t.res, nb_conn, extend_c, (unsigned)l, t, t.sel);
+            std::stable_sort(t.sel.begin(), t.sel.end(), EdgeLess());  // :1195
+            {
+                SpinGuard g(np.lock);
+                np.list((unsigned)l) = t.sel;  // :1197
+            }
+            dirty.push_back((id << 4) | (uint32_t)l);
+        }
+    }
+    // reverse_update_neighborhood_simple (:1210), remembering which lists of the snapshot are now out of date
+    for (int l = (int)level; l >= 0; --l) {
+        read_list(id, (unsigned)l, t.tmp);
+        for (const Edge& q : t.tmp)
+            if (q.id != id) dirty.push_back((q.id << 4) | level);
+    }
+    reverse_update(id, t);
+    {   // check_entry_point (src/hnsw.rs:534-557)
+        std::lock_guard<std::mutex> g(entry_mutex_);
+        if ((int)level > entry_level_.load()) {
+            entry_level_.store((int)level);
+            entry_.store(id, std::memory_order_release);
+        }
+    }
+}
+
+int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
+                                   BuildSearchBackend& dev, uint64_t max_window, std::string& err) {
+    if (n == 0) return OK;
+    if (n_ + n >= (1ull << 28)) { err = "GPU-assisted construction: too many points (dirty-list ids are 28 bits)"; return ERR_ARG; }
+    const uint64_t first = n_;
+    int rc = append_points(data, n, d, ids, err);
+    if (rc != OK) return rc;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    if (max_window == 0) max_window = 16384;
+    // bootstrap on the host: the first points (a window that cannot see itself needs a graph to search in)
+    uint64_t start = first;
+    Tls t0;
+    const uint64_t boot_until = max_window == 1 ? std::min<uint64_t>(n_, std::max<uint64_t>(first, 1)) : std::min<uint64_t>(n_, std::max<uint64_t>(first, 1024));
+    for (; start < boot_until; ++start) insert_one((uint32_t)start, t0);
+    if (start >= n_) return OK;
+    // the device gets every vector and level, and the lists as they are now
+    unsigned top_layer = 0;
+    std::vector<uint8_t> levels(n_);
+    for (uint64_t i = 0; i < n_; ++i) { levels[i] = node((uint32_t)i).level; top_layer = std::max<unsigned>(top_layer, levels[i]); }
+    std::vector<const float*> chunk_ptrs;
+    for (auto& c : vecs_) chunk_ptrs.push_back(c.get());
+    rc = dev.begin(chunk_ptrs.data(), CHUNK, n_, d_, levels.data(), p_.dist, p_.max_nb_connection, p_.ef_construction, top_layer,
+                   max_window, err);
+    if (rc != OK) return rc;
+    const uint32_t rw = dev.rec_words();
+    std::vector<uint32_t> records;
+    auto pack = [&](const std::vector<uint32_t>& dirty) {
+        records.clear();
+        records.reserve(dirty.size() * rw);
+        for (uint32_t key : dirty) {
+            const uint32_t id = key >> 4, l = key & 15u;
+            const size_t base = records.size();
+            records.resize(base + rw, NO_POINT);
+            records[base] = id;
+            records[base + 1] = l;
+            Node& nd = node(id);
+            SpinGuard g(nd.lock);
+            const std::vector<Edge>* lst = nd.list_if(l);
+            if (lst)
+                for (size_t j = 0; j < lst->size() && j + 2 < rw; ++j) records[base + 2 + j] = (*lst)[j].id;
+        }
+    };
+    {   // initial snapshot: every list of the points inserted so far
+        std::vector<uint32_t> dirty;
+        for (uint64_t i = 0; i < start; ++i)
+            for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
+                const std::vector<Edge>* lst = node((uint32_t)i).list_if(l);
+                if (lst && !lst->empty()) dirty.push_back(((uint32_t)i << 4) | l);
+            }
+        pack(dirty);
+        rc = dev.patch(records, err);
+        if (rc != OK) return rc;
+    }
+    WindowSearchResults res;
+    std::vector<std::vector<uint32_t>> dirty_t((size_t)nthreads);
+    while (start < n_) {
+        const uint64_t grown = max_window == 1 ? 1 : std::max<uint64_t>(256, start / 8);
+        const uint32_t count = (uint32_t)std::min<uint64_t>({n_ - start, max_window, grown});
+        const uint32_t frozen_entry = (uint32_t)entry_.load(std::memory_order_acquire);
+        const unsigned frozen_level = (unsigned)entry_level_.load();
+        uint32_t layer_mask = 0;
+        for (unsigned l = 0; l < NB_LAYER_MAX; ++l)
+            if (layer_inserted_[l].load(std::memory_order_acquire) > 0) layer_mask |= 1u << l;
+        rc = dev.search_window((uint32_t)start, count, frozen_entry, frozen_level, layer_mask, res, err);
+        if (rc != OK) return rc;
+        for (auto& v : dirty_t) v.clear();
+        std::atomic<uint32_t> next{0};
+        auto worker = [&](int tid) {
+            Tls t;
+            for (;;) {
+                const uint32_t wi = next.fetch_add(1);
+                if (wi >= count) break;
+                apply_window_point((uint32_t)start + wi, wi, frozen_entry, frozen_level, layer_mask, res, p_.ef_construction, t, dirty_t[(size_t)tid]);
+            }
+        };
+        const int nt = (int)std::min<uint64_t>((uint64_t)nthreads, std::max<uint32_t>(1, count / 8));
+        std::vector<std::thread> th;
+        for (int k = 1; k < nt; ++k) th.emplace_back(worker, k);
+        worker(0);
+        for (auto& x : th) x.join();
+        std::vector<uint32_t> dirty;
+        for (auto& v : dirty_t) dirty.insert(dirty.end(), v.begin(), v.end());
+        std::sort(dirty.begin(), dirty.end());
+        dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+        pack(dirty);
+        rc = dev.patch(records, err);
+        if (rc != OK) return rc;
+        start += count;
+    }
     return OK;
 }
 

@@ -26,11 +26,39 @@ struct BuildParams {
     bool keep_pruned = false;
     int nthreads = 0;            // 1 = serial (deterministic), 0 = hardware_concurrency
     bool fast_arithmetic = false;  // false: reference-order scalar sums
+    int gpu_device = -1;         // >= 0: GPU-assisted construction (insert_batch_gpu) on that device
+    uint64_t gpu_window = 0;     // 0 = default window cap
 };
 
 struct Edge {
     uint32_t id;  // builder id = insertion order
     float dist;
+};
+
+// What the device returns for one window of points (GPU-assisted construction): the results of the searches of
+// insert_slice (src/hnsw.rs:1114-1197) against the snapshot the device holds.
+struct WindowSearchResults {
+    std::vector<uint32_t> slot0;    // [count] slot of point i's layer-0 search; layer l -> slot0[i] + l
+    std::vector<uint32_t> out_ids;  // [slots][ef_c] candidates, ascending distance (builder ids)
+    std::vector<float> out_d;
+    std::vector<uint32_t> out_n;    // [slots]
+    std::vector<uint32_t> hit_ids;  // [count][NB_LAYER_MAX] ef = 1 hit per layer above the point's level (NO_POINT: none)
+    std::vector<float> hit_d;
+};
+// The device side of GPU-assisted construction (implemented in search_device.hip; builder.cpp stays free of HIP).
+class BuildSearchBackend {
+public:
+    virtual ~BuildSearchBackend() = default;
+    // all vectors of the build (builder order, n x d) and every point's level; empty lists everywhere
+    virtual int begin(const float* const* chunks, uint64_t chunk_rows, uint64_t n, uint64_t d, const uint8_t* levels, int dist,
+                      uint64_t max_nb_connection, uint64_t ef_construction, unsigned top_layer, uint64_t max_window,
+                      std::string& err) = 0;
+    // replace lists of the snapshot: records of rec_words() u32 = {node, layer, ids..., NO_POINT padding}
+    virtual uint32_t rec_words() const = 0;
+    virtual int patch(const std::vector<uint32_t>& records, std::string& err) = 0;
+    // layer_mask: bit l set when some inserted point has level exactly l (search_layer returns nothing on other layers)
+    virtual int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask,
+                              WindowSearchResults& out, std::string& err) = 0;
 };
 
 class GraphBuilder {
@@ -44,6 +72,11 @@ public:
     ~GraphBuilder();
     // insert n points (row-major n x d).  ids == nullptr: origin ids continue from nb_point().
     int insert_batch(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads, std::string& err);
+    // The same with the searches of every insertion done on the device, window by window against a frozen snapshot
+    // (points of one window do not see each other; windows grow with the graph: max(256, inserted / 8) up to max_window),
+    // select_neighbours + list updates + reverse updates on the host cores.  window == 1 reproduces the serial insertion.
+    int insert_batch_gpu(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads, BuildSearchBackend& dev,
+                         uint64_t max_window, std::string& err);
     uint64_t nb_point() const { return n_; }
     uint64_t dimension() const { return d_; }
     const BuildParams& params() const { return p_; }
@@ -59,6 +92,9 @@ private:
     float eval(const float* a, const float* b) const;
     size_t draw_level();
     void insert_one(uint32_t id, Tls& t);
+    int append_points(const float* data, uint64_t n, uint64_t d, const uint64_t* ids, std::string& err);
+    void apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_entry, unsigned frozen_entry_level, uint32_t layer_mask,
+                            const WindowSearchResults& r, uint64_t ef_c, Tls& t, std::vector<uint32_t>& dirty);
     void search_layer(const float* q, uint32_t entry, size_t ef, unsigned layer, Tls& t, std::vector<Edge>& out_sorted);
     void select_neighbours(const float* q, std::vector<Edge>& cands_sorted, size_t nb_asked, bool extend_asked,
                            unsigned layer, Tls& t, std::vector<Edge>& out);

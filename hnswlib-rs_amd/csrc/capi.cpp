@@ -196,6 +196,8 @@ static BuildParams to_params(const hnswgpu_build_params* p) {
     b.keep_pruned = p->keep_pruned != 0;
     b.nthreads = p->nthreads;
     b.fast_arithmetic = p->fast_arithmetic != 0;
+    b.gpu_device = p->gpu_assist ? p->gpu_device : -1;
+    b.gpu_window = p->gpu_window;
     return b;
 }
 
@@ -211,7 +213,13 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
     h->params = to_params(params);
     h->builder.reset(new GraphBuilder(h->params));
     std::string err;
-    int rc = h->builder->insert_batch(data, n, d, ids, h->params.nthreads, err);
+    int rc;
+    if (h->params.gpu_device >= 0) {
+        std::unique_ptr<BuildSearchBackend> dev = make_device_build_backend(h->params.gpu_device);
+        rc = h->builder->insert_batch_gpu(data, n, d, ids, h->params.nthreads, *dev, h->params.gpu_window, err);
+    } else {
+        rc = h->builder->insert_batch(data, n, d, ids, h->params.nthreads, err);
+    }
     if (rc != OK) return fail(rc, err);
     h->flat_stale = true;
     *out = h.release();
@@ -221,14 +229,21 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
 
 // Hnsw::insert / parallel_insert on ANY handle, reloaded ones included (HnswIo::load_hnsw returns a fully insertable
 // Hnsw).  Exclusive lock held by the caller.
-static int insert_points(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads) {
+static int insert_points(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
+                         int gpu_device = -1, uint64_t gpu_window = 0) {
     if (!idx->builder) {
         if (!idx->flat) return fail(HNSWGPU_ERR_EMPTY, "handle holds no index");
         idx->builder.reset(new GraphBuilder(*idx->flat, false));  // continue the reloaded graph (builder.hpp)
         idx->params = idx->builder->params();
     }
     std::string err;
-    int rc = idx->builder->insert_batch(data, n, d, ids, nthreads, err);
+    int rc;
+    if (gpu_device >= 0) {
+        std::unique_ptr<BuildSearchBackend> dev = make_device_build_backend(gpu_device);
+        rc = idx->builder->insert_batch_gpu(data, n, d, ids, nthreads, *dev, gpu_window, err);
+    } else {
+        rc = idx->builder->insert_batch(data, n, d, ids, nthreads, err);
+    }
     if (rc != OK) return fail(rc, err);
     idx->flat_stale = true;
     idx->dev_stale = true;
@@ -240,6 +255,16 @@ int hnswgpu_insert(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d
     if (!idx || (n && !data)) return fail(HNSWGPU_ERR_ARG, "null argument");
     std::unique_lock<std::shared_mutex> g(idx->mu);
     return insert_points(idx, data, n, d, ids, nthreads);
+    CAPI_GUARD_END(HNSWGPU_ERR_ARG)
+}
+
+int hnswgpu_insert_gpu(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
+                       int gpu_device, uint64_t gpu_window) {
+    CAPI_GUARD_BEGIN
+    if (!idx || (n && !data)) return fail(HNSWGPU_ERR_ARG, "null argument");
+    if (gpu_device < 0) return fail(HNSWGPU_ERR_ARG, "gpu_device must name a HIP device");
+    std::unique_lock<std::shared_mutex> g(idx->mu);
+    return insert_points(idx, data, n, d, ids, nthreads, gpu_device, gpu_window);
     CAPI_GUARD_END(HNSWGPU_ERR_ARG)
 }
 

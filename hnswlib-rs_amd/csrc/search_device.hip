@@ -494,7 +494,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         const KernelSet& ks = kernel_set(dist_);
         const bool strict_kernel = strict_ties && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
         if (strict_kernel) {  // top levels of the literal candidate heap, for the few queries that need it
-            a.cand_lds = 256;
+            a.cand_lds = 512;
             lds += (size_t)a.cand_lds * sizeof(hent_t);
         }
         int per_cu = 0;
@@ -643,6 +643,183 @@ int DeviceIndex::search_host(const float* queries, uint64_t nq, uint64_t d, uint
     if (out_status)
         for (uint64_t i = 0; i < nq; ++i) out_status[i] = st[i * 8 + 3] == 6u ? 1 : 0;
     return OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GPU-assisted construction: the device holds every vector of the build and a snapshot of the neighbour lists (one
+// fixed-stride array per layer, builder ids); search_window runs hnsw_build_search_kernel for a window of new points,
+// patch() brings the snapshot up to date with what the host did with the results (builder.cpp).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+class DeviceBuildBackend : public BuildSearchBackend {
+public:
+    explicit DeviceBuildBackend(int device) : device_(device) {}
+    ~DeviceBuildBackend() override {
+        if (device_ >= 0) (void)hipSetDevice(device_);
+        for (DevBuf* b : {&vec_, &level_, &nrm2_, &slot0_, &out_ids_, &out_d_, &out_n_, &hit_ids_, &hit_d_, &bitmap_, &upd_}) b->free();
+        for (auto& b : lists_) b.free();
+        if (d_ctrl_) (void)hipFree(d_ctrl_);
+    }
+    int begin(const float* const* chunks, uint64_t chunk_rows, uint64_t n, uint64_t d, const uint8_t* levels, int dist,
+              uint64_t max_nb_connection, uint64_t ef_construction, unsigned top_layer, uint64_t max_window, std::string& err) override {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device visible (GPU-assisted construction needs a gfx950 GPU)"; return ERR_DEVICE; }
+        if (device_ < 0 || device_ >= ndev) { err = "bad device ordinal"; return ERR_ARG; }
+        if (ef_construction > 1024) { err = "GPU-assisted construction supports ef_construction up to 1024"; return ERR_ARG; }
+        HIP_TRY(hipSetDevice(device_));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_));
+        num_cu_ = prop.multiProcessorCount;
+        n_ = n;
+        dist_ = dist;
+        ef_c_ = (uint32_t)ef_construction;
+        row_stride_ = (uint32_t)((d + 31) / 32 * 32);
+        max_window_ = (uint32_t)std::max<uint64_t>(1, max_window);
+        top_layer_ = std::min<unsigned>(top_layer, NB_LAYER_MAX - 1);
+        // vectors, padded rows
+        HIP_TRY(vec_.ensure(n * row_stride_ * sizeof(float)));
+        HIP_TRY(hipMemset(vec_.p, 0, n * row_stride_ * sizeof(float)));
+        for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+            const uint64_t rows = std::min<uint64_t>(chunk_rows, n - r0);
+            HIP_TRY(hipMemcpy2D(vec_.as<float>() + r0 * row_stride_, row_stride_ * sizeof(float), chunks[r0 / chunk_rows], d * sizeof(float),
+                                d * sizeof(float), rows, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(level_.ensure(n));
+        HIP_TRY(hipMemcpy(level_.p, levels, n, hipMemcpyHostToDevice));
+        if (dist == DIST_COSINE) {
+            HIP_TRY(nrm2_.ensure(n * sizeof(double)));
+            HIP_TRY(launch_row_sq_norms(nullptr, vec_.as<float>(), nrm2_.as<double>(), (uint32_t)n, row_stride_));
+        }
+        // neighbour lists: layer 0 holds up to 2M ids, the others up to M
+        bl_ = BuildLists{};
+        max_stride_ = 0;
+        for (unsigned l = 0; l <= top_layer_; ++l) {
+            const uint32_t stride = (uint32_t)(((l == 0 ? 2 : 1) * max_nb_connection + 15) / 16 * 16);
+            HIP_TRY(lists_[l].ensure(n * stride * sizeof(uint32_t)));
+            HIP_TRY(hipMemset(lists_[l].p, 0xFF, n * stride * sizeof(uint32_t)));
+            bl_.lists[l] = lists_[l].as<uint32_t>();
+            bl_.stride[l] = stride;
+            max_stride_ = std::max(max_stride_, stride);
+        }
+        HIP_TRY(hipMalloc(&d_ctrl_, 64));
+        HIP_TRY(hipDeviceSynchronize());
+        return OK;
+    }
+    uint32_t rec_words() const override { return 2u + max_stride_; }
+    int patch(const std::vector<uint32_t>& records, std::string& err) override {
+        if (records.empty()) return OK;
+        HIP_TRY(hipSetDevice(device_));
+        const uint32_t rw = rec_words();
+        const uint32_t n_upd = (uint32_t)(records.size() / rw);
+        for (uint32_t u = 0; u < n_upd; ++u)
+            if (records[(size_t)u * rw + 1] > top_layer_ || records[(size_t)u * rw] >= n_) { err = "internal error: list update outside the snapshot"; return ERR_ARG; }
+        HIP_TRY(upd_.ensure(records.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(upd_.p, records.data(), records.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(launch_scatter_lists(nullptr, upd_.as<uint32_t>(), n_upd, rw, bl_));
+        HIP_TRY(hipDeviceSynchronize());
+        return OK;
+    }
+    int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask, WindowSearchResults& out,
+                      std::string& err) override {
+        HIP_TRY(hipSetDevice(device_));
+        if (entry_level > top_layer_) { err = "internal error: entry point above the snapshot's layers"; return ERR_ARG; }
+        // output slots: one per (point, layer <= min(level, entry level))
+        levels_h_.resize(count);
+        HIP_TRY(hipMemcpy(levels_h_.data(), level_.as<uint8_t>() + first, count, hipMemcpyDeviceToHost));
+        out.slot0.resize(count);
+        uint64_t slots = 0;
+        for (uint32_t i = 0; i < count; ++i) {
+            out.slot0[i] = (uint32_t)slots;
+            slots += std::min<uint32_t>(levels_h_[i], entry_level) + 1u;
+        }
+        HIP_TRY(slot0_.ensure(count * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(slot0_.p, out.slot0.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(out_ids_.ensure(slots * ef_c_ * sizeof(uint32_t)));
+        HIP_TRY(out_d_.ensure(slots * ef_c_ * sizeof(float)));
+        HIP_TRY(out_n_.ensure(slots * sizeof(uint32_t)));
+        HIP_TRY(hit_ids_.ensure((uint64_t)count * NB_LAYER_MAX * sizeof(uint32_t)));
+        HIP_TRY(hit_d_.ensure((uint64_t)count * NB_LAYER_MAX * sizeof(float)));
+        HIP_TRY(hipMemset(hit_ids_.p, 0xFF, (uint64_t)count * NB_LAYER_MAX * sizeof(uint32_t)));
+
+        BuildArgs a{};
+        a.vec = vec_.as<float>();
+        a.row_stride = row_stride_;
+        for (unsigned l = 0; l < NB_LAYER_MAX; ++l) { a.lists[l] = bl_.lists[l]; a.stride[l] = bl_.stride[l]; }
+        a.level = level_.as<uint8_t>();
+        a.slot0 = slot0_.as<uint32_t>();
+        a.first = first;
+        a.count = count;
+        a.entry = entry;
+        a.entry_level = entry_level;
+        a.layer_mask = layer_mask;
+        a.ef_c = ef_c_;
+        int slots_per_lane = 1;
+        while ((uint32_t)slots_per_lane * 64u < ef_c_) slots_per_lane *= 2;
+        if (slots_per_lane == 8) slots_per_lane = 16;
+        // visited table: ef_c x degree cells (the construction search visits about that many points), 16-bit cells
+        const uint32_t idbits = std::max<uint32_t>(1u, ceil_log2(n_));
+        uint32_t tbits = std::min<uint32_t>(14u, std::max<uint32_t>(8u, ceil_log2((uint64_t)ef_c_ * std::min<uint32_t>(bl_.stride[0], 64u))));
+        tbits = std::max(3u, std::min(tbits, idbits + 3u));
+        while (idbits - (tbits - 3u) > 13u && tbits < 16u) ++tbits;  // (16-bit cells keep at most 13 id bits)
+        if (idbits - (tbits - 3u) > 13u) { err = "GPU-assisted construction: index too large for the 16-bit visited cells"; return ERR_ARG; }
+        a.tbits = tbits;
+        a.idbits = idbits;
+        a.restbits = idbits - (tbits - 3u);
+        a.tile_bytes = tile_bytes_for(dist_, row_stride_);
+        const size_t lds = a.tile_bytes + IDS_BYTES + ((size_t)2 << tbits);
+        const KernelSet& ks = kernel_set(dist_);
+        int per_cu = 0;
+        HIP_TRY(ks.build_occupancy(slots_per_lane, lds, &per_cu));
+        if (per_cu < 1) per_cu = 1;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, count);
+        a.bitmap_words = (uint32_t)((n_ + 31) / 32);
+        HIP_TRY(bitmap_.ensure((uint64_t)grid * a.bitmap_words * sizeof(uint32_t)));
+        a.bitmap = bitmap_.as<uint32_t>();
+        a.bitmap_blocks = grid;
+        a.work_counter = static_cast<uint32_t*>(d_ctrl_);
+        a.fail_count = static_cast<uint32_t*>(d_ctrl_) + 1;
+        a.out_ids = out_ids_.as<uint32_t>();
+        a.out_d = out_d_.as<float>();
+        a.out_n = out_n_.as<uint32_t>();
+        a.hit_ids = hit_ids_.as<uint32_t>();
+        a.hit_d = hit_d_.as<float>();
+        a.nrm2 = nrm2_.as<double>();
+        HIP_TRY(hipMemset(d_ctrl_, 0, 8));
+        HIP_TRY(ks.launch_build_search(slots_per_lane, grid, lds, nullptr, a));
+        uint32_t ctrl[2] = {0, 0};
+        HIP_TRY(hipMemcpy(ctrl, d_ctrl_, 8, hipMemcpyDeviceToHost));
+        if (ctrl[1] != 0) { err = "internal error: visited set overflow in the construction search"; return ERR_DEVICE; }
+        out.out_ids.resize(slots * ef_c_);
+        out.out_d.resize(slots * ef_c_);
+        out.out_n.resize(slots);
+        out.hit_ids.resize((size_t)count * NB_LAYER_MAX);
+        out.hit_d.resize((size_t)count * NB_LAYER_MAX);
+        HIP_TRY(hipMemcpy(out.out_ids.data(), out_ids_.p, slots * ef_c_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.out_d.data(), out_d_.p, slots * ef_c_ * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.out_n.data(), out_n_.p, slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.hit_ids.data(), hit_ids_.p, (size_t)count * NB_LAYER_MAX * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.hit_d.data(), hit_d_.p, (size_t)count * NB_LAYER_MAX * sizeof(float), hipMemcpyDeviceToHost));
+        return OK;
+    }
+
+private:
+    int device_;
+    int num_cu_ = 0;
+    int dist_ = DIST_L2;
+    uint64_t n_ = 0;
+    uint32_t ef_c_ = 0, row_stride_ = 0, max_window_ = 1, max_stride_ = 0;
+    unsigned top_layer_ = 0;
+    DevBuf vec_, level_, nrm2_, slot0_, out_ids_, out_d_, out_n_, hit_ids_, hit_d_, bitmap_, upd_;
+    DevBuf lists_[NB_LAYER_MAX];
+    BuildLists bl_{};
+    void* d_ctrl_ = nullptr;
+    std::vector<uint8_t> levels_h_;
+};
+}  // namespace
+
+std::unique_ptr<BuildSearchBackend> make_device_build_backend(int device) {
+    return std::unique_ptr<BuildSearchBackend>(new DeviceBuildBackend(device));
 }
 
 int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include "builder.hpp"
 #include "flat_index.hpp"
 
 namespace hnswgpu {
@@ -110,6 +111,8 @@ private:
 };
 
 int device_count();
+// the device side of GPU-assisted construction (builder.hpp) on HIP device `device`
+std::unique_ptr<BuildSearchBackend> make_device_build_backend(int device);
 // Distance<f32>::eval on the device through the search kernel's own distance routine: out[q][r] = dist(queries[q],
 // rows[r]), rows evaluated in batches of `nf` (1..64) -- the lane-group branches the search takes for nf neighbours.
 // pairs: nq == n and out[i] = dist(queries[i], rows[i]) (nf ignored).

@@ -61,6 +61,35 @@ struct ExactArgs {
     const uint32_t* allow;  // filtered search: one bit per flat id (nullptr = Hnsw::search, no filter)
 };
 
+// the snapshot's neighbour lists during construction: one fixed-stride array per layer (builder ids, EMPTY padded)
+struct BuildLists {
+    uint32_t* lists[NB_LAYER_MAX];   // [n][stride[l]]; nullptr above the highest layer of the build
+    uint32_t stride[NB_LAYER_MAX];
+};
+struct BuildArgs {
+    const float* vec;         // [n][row_stride] every vector of the build, builder order (= insertion order), zero padded
+    uint32_t row_stride;
+    const uint32_t* lists[NB_LAYER_MAX];
+    uint32_t stride[NB_LAYER_MAX];
+    const uint8_t* level;     // [n] level of every point
+    const uint32_t* slot0;    // [count] output slot of the window's i-th point at layer 0 (layer l: slot0[i] + l)
+    uint32_t first, count;    // the window: builder ids first .. first + count - 1
+    uint32_t entry, entry_level;  // the frozen entry point
+    uint32_t layer_mask;      // bit l: some inserted point has level exactly l (points_by_layer[l] is not empty)
+    uint32_t ef_c;
+    uint32_t tbits, idbits, restbits, tile_bytes;
+    uint32_t* bitmap;
+    uint32_t bitmap_words, bitmap_blocks;
+    uint32_t* work_counter;
+    uint32_t* fail_count;
+    uint32_t* out_ids;        // [slots][ef_c] candidates of an ef_construction search, ascending distance
+    float* out_d;
+    uint32_t* out_n;          // [slots]
+    uint32_t* hit_ids;        // [count][NB_LAYER_MAX] ef = 1 result of the layers above the point's level (EMPTY_SLOT: none)
+    float* hit_d;
+    const double* nrm2;
+};
+
 // One translation unit per metric instantiates the kernels (keeps the build parallel and the objects small).
 struct KernelSet {
     // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (decisions that depend on the
@@ -78,6 +107,9 @@ struct KernelSet {
     // out[q] = dist(queries[q], rows[q])
     hipError_t (*launch_eval_matrix)(hipStream_t stream, const float* queries, uint32_t nq, const float* rows, uint32_t n_rows,
                                      const double* nrm2, float* out, uint32_t row_stride, uint32_t nf, bool pairs);
+    // construction: the searches of insert_slice for a window of points (hnsw_build_search_kernel)
+    hipError_t (*launch_build_search)(int slots, uint32_t grid, size_t lds, hipStream_t stream, const BuildArgs& a);
+    hipError_t (*build_occupancy)(int slots, size_t lds, int* per_cu);
 };
 // LDS in front of the id buffer: the query row; DistCosine keeps the query's squared norm (f64) behind it
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
@@ -90,5 +122,6 @@ const KernelSet& kernels_l1();
 // metric-independent helpers (instantiated once, in the L2 translation unit)
 hipError_t launch_allow_bitmap(hipStream_t stream, const uint64_t* origin_id, uint32_t n, const uint64_t* ids, uint64_t m, uint32_t* allow);
 hipError_t launch_row_sq_norms(hipStream_t stream, const float* vec, double* out, uint32_t n, uint32_t row_stride);
+hipError_t launch_scatter_lists(hipStream_t stream, const uint32_t* upd, uint32_t n_upd, uint32_t rec_words, const BuildLists& lists);
 
 }  // namespace hnswgpu

@@ -87,8 +87,9 @@ int hnswgpu_get_description(const hnswgpu_index* idx, hnswgpu_description* out);
 
 /* ---------------------------------------------------------------- construction ------- */
 /* Hnsw::<f32, D>::new(max_nb_connection, max_elements, max_layer, ef_construction, D)
- * + (parallel_)insert of n points (src/hnsw.rs:771, :1077-1215, :1224-1238).  Host (CPU)
- * construction; levels come from the documented SplitMix64(397) stream.   */
+ * + (parallel_)insert of n points (src/hnsw.rs:771, :1077-1215, :1224-1238).  Construction on
+ * the host cores, or GPU-assisted (gpu_device); levels come from the documented
+ * SplitMix64(397) stream.                                                */
 typedef struct {
     uint64_t max_nb_connection; /* M; layer-0 lists hold up to 2M                         */
     uint64_t ef_construction;
@@ -100,6 +101,13 @@ typedef struct {
     int nthreads;               /* 1 = serial insert (deterministic); 0 = all host cores  */
     int fast_arithmetic;        /* 0: reference-order scalar sums; 1: 8-lane SIMD sums
                                    (the crate's `simdeez_f` build order)                  */
+    int gpu_assist;             /* 1: GPU-assisted construction: the searches of every insertion
+                                   (src/hnsw.rs:1114-1197) run on HIP device gpu_device, window by window against a
+                                   frozen snapshot of the graph; select_neighbours, list and reverse updates on the
+                                   host cores.  0 (default): host only.  Device distances are reference-order.      */
+    int gpu_device;
+    uint64_t gpu_window;        /* points per window at most (0 = 16384); windows grow with the graph
+                                   (max(256, inserted / 8)); 1 = one point at a time: the serial insertion, exactly */
 } hnswgpu_build_params;
 int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids /* NULL: 0..n-1 */,
                   const hnswgpu_build_params* params, hnswgpu_index** out);
@@ -110,6 +118,9 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
  * kept).  nthreads: 1 = serial, 0 = all host cores.  HBM replicas are refreshed by the next search / upload.           */
 int hnswgpu_insert(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids /* NULL: continue */,
                    int nthreads);
+/* the same, GPU-assisted (see hnswgpu_build_params.gpu_assist / gpu_device / gpu_window)                                 */
+int hnswgpu_insert_gpu(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
+                       int gpu_device, uint64_t gpu_window);
 
 /* ---------------------------------------------------------------- inspection --------- */
 uint64_t hnswgpu_nb_point(const hnswgpu_index* idx);

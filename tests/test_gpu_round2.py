@@ -242,3 +242,55 @@ def test_full_size_parity_200k_x_128(native, oracle, tmp_path, monkeypatch):
 def test_full_size_parity_config5_60k_x_784(native, oracle, tmp_path, monkeypatch):
     """BASELINE config 5 at its real size: 60 000 x 784, M = 32 (64 ids per row), ef = 200 (4 result slots per lane)."""
     _full_size_case(native, oracle, tmp_path, monkeypatch, 60_000, 784, 32, 400, 10, 200, 2000, 600)
+
+
+# ------------------------------------------------------------------------------------------------- construction
+@pytest.mark.parametrize("dist,d,m,efc,scale", [("DistL2", 16, 12, 60, None), ("DistCosine", 25, 8, 100, None), ("DistL1", 10, 10, 40, 0.5),
+                                                ("DistDot", 12, 6, 250, None)])
+def test_gpu_assisted_construction_window_1_equals_the_serial_insertion(native, oracle, tmp_path, dist, d, m, efc, scale):
+    """GPU-assisted construction with one point per window: every search_layer of insert_slice (ef = 1 above the point's
+    level, ef_construction from its level down, src/hnsw.rs:1114-1197) runs on the device against the graph built so far,
+    everything else on the host.  The graph must be the oracle's serially built graph BYTE FOR BYTE -- i.e. every
+    candidate heap the device returned equals the reference's search_layer on the same partial graph (ef_construction 250
+    uses 4 result slots per lane)."""
+    n = 1500
+    X = normalized(n, d, 91) if dist == "DistDot" else uniform(n, d, 91)
+    o = oracle.OracleHnsw(m, n, 16, efc, dist)
+    if scale is not None:
+        o.modify_level_scale(scale)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "orc")
+    h = native.Hnsw(m, n, 16, efc, dist)
+    if scale is not None:
+        h.modify_level_scale(scale)
+    h.set_build_options(nthreads=1, gpu_device=0, gpu_window=1)
+    h.parallel_insert(X)
+    h.file_dump(tmp_path, "gpu")
+    for ext in (".hnsw.graph", ".hnsw.data"):
+        assert open(tmp_path / ("orc" + ext), "rb").read() == open(tmp_path / ("gpu" + ext), "rb").read()
+
+
+def test_gpu_assisted_construction_windows_build_a_graph_as_good(native, oracle, tmp_path):
+    """Windows of many points (they do not see each other; the reference's parallel_insert is racy too): the graph is
+    not the serial one, but it must search as well -- recall@10 against brute force within a point of the host builder's
+    -- and the product's search of it must still equal the oracle's search of the same dump."""
+    n, d, k, ef = 60_000, 32, 10, 64
+    X = _clustered(n, d, 7)
+    Q = _clustered(500, d, 8)
+    d2 = (Q.astype(np.float64) ** 2).sum(1)[:, None] + (X.astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * Q.astype(np.float64) @ X.astype(np.float64).T
+    gt = np.argsort(d2, axis=1)[:, :k]
+    recalls = {}
+    for name, opts in (("host", dict(nthreads=0)), ("gpu", dict(nthreads=0, gpu_device=0, gpu_window=4096))):
+        h = native.Hnsw(16, n, 16, 200, "DistL2")
+        h.set_build_options(fast_arithmetic=False, **opts)
+        h.parallel_insert(X)
+        assert h.get_nb_point() == n
+        h.file_dump(tmp_path, name)
+        h.upload(0)
+        res = h.parallel_search_flat(Q, k, ef)
+        recalls[name] = np.mean([len(set(res.ids[i].tolist()) & set(gt[i].tolist())) / k for i in range(500)])
+        if name == "gpu":
+            o = oracle.OracleHnsw.load(tmp_path, name, "DistL2")
+            assert_same(res, o.parallel_search(Q, k, ef))
+    assert recalls["gpu"] > recalls["host"] - 0.01, recalls
+    assert recalls["gpu"] > 0.9, recalls
