@@ -90,6 +90,14 @@ SYMBOLS = {
     "hnswgpu_free_index": (None, [_VP]),
     "hnswgpu_load_description": (_I, [C.c_char_p, C.POINTER(Description)]),
     "hnswgpu_get_description": (_I, [_VP, C.POINTER(Description)]),
+    "hnswgpu_datamap_open": (_I, [C.c_char_p, C.c_char_p, C.POINTER(_VP)]),
+    "hnswgpu_datamap_close": (None, [_VP]),
+    "hnswgpu_datamap_get_data": (_VP, [_VP, _U64]),
+    "hnswgpu_datamap_nb_data": (_U64, [_VP]),
+    "hnswgpu_datamap_dimension": (_U64, [_VP]),
+    "hnswgpu_datamap_distname": (C.c_char_p, [_VP]),
+    "hnswgpu_datamap_typename": (C.c_char_p, [_VP]),
+    "hnswgpu_datamap_ids": (_U64, [_VP, _VP, _U64]),
     "hnswgpu_build": (_I, [_VP, _U64, _U64, _VP, C.POINTER(BuildParams), C.POINTER(_VP)]),
     "hnswgpu_insert": (_I, [_VP, _VP, _U64, _U64, _VP, _I]),
     "hnswgpu_insert_gpu": (_I, [_VP, _VP, _U64, _U64, _VP, _I, _I, _U64]),

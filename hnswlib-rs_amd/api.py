@@ -312,6 +312,55 @@ class HnswIo:
         return Hnsw(_handle=h.value)
 
 
+class DataMap:
+    """hnsw_rs::datamap::DataMap (src/datamap.rs): the vectors of a dump by DataId, memory-mapped, graph not loaded."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def from_hnswdump(directory, file_name):
+        h = C.c_void_p()
+        _check(N.lib().hnswgpu_datamap_open(str(directory).encode(), file_name.encode(), C.byref(h)))
+        return DataMap(h.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().hnswgpu_datamap_close(h)
+
+    def get_data(self, dataid):
+        """Option<&[f32]>: a read-only view into the mapping (valid while this object lives), or None."""
+        p = N.lib().hnswgpu_datamap_get_data(self._h, int(dataid))
+        if not p:
+            return None
+        d = self.get_dimension()
+        a = np.ctypeslib.as_array((C.c_float * d).from_address(p))
+        a.flags.writeable = False
+        return a
+
+    def get_nb_data(self):
+        return N.lib().hnswgpu_datamap_nb_data(self._h)
+
+    def get_dimension(self):
+        return N.lib().hnswgpu_datamap_dimension(self._h)
+
+    def get_distname(self):
+        return N.lib().hnswgpu_datamap_distname(self._h).decode()
+
+    def get_data_typename(self):
+        return N.lib().hnswgpu_datamap_typename(self._h).decode()
+
+    def check_data_type(self, type_name):
+        return type_name.rsplit("::", 1)[-1] == self.get_data_typename().rsplit("::", 1)[-1]
+
+    def get_dataid_iter(self):
+        n = self.get_nb_data()
+        out = np.zeros(n, np.uint64)
+        N.lib().hnswgpu_datamap_ids(self._h, _p(out), n)
+        return out.tolist()
+
+
 def load_description(graph_file_path):
     """load_description (src/hnswio.rs:937-1042) of a <basename>.hnsw.graph file."""
     d = N.Description()

@@ -13,6 +13,7 @@
 
 #include "../../include/hnsw_mi355x.h"
 #include "builder.hpp"
+#include "datamap.hpp"
 #include "flat_index.hpp"
 #include "hnswio.hpp"
 #include "search_device.hpp"
@@ -570,6 +571,35 @@ int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, co
     if (rc != OK) return fail(rc, err);
     return HNSWGPU_OK;
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
+// ---- DataMap (src/datamap.rs): the vectors of a dump by DataId, memory-mapped, without loading the graph
+struct hnswgpu_datamap {
+    DataMap m;
+};
+int hnswgpu_datamap_open(const char* dir, const char* basename, hnswgpu_datamap** out) {
+    CAPI_GUARD_BEGIN
+    if (!dir || !basename || !out) return fail(HNSWGPU_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::unique_ptr<hnswgpu_datamap> h(new hnswgpu_datamap());
+    std::string err;
+    int rc = h->m.open(dir, basename, err);
+    if (rc != OK) return fail(rc, err);
+    *out = h.release();
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_IO)
+}
+void hnswgpu_datamap_close(hnswgpu_datamap* m) { delete m; }
+const float* hnswgpu_datamap_get_data(const hnswgpu_datamap* m, uint64_t data_id) { return m ? m->m.get_data(data_id) : nullptr; }
+uint64_t hnswgpu_datamap_nb_data(const hnswgpu_datamap* m) { return m ? m->m.nb_data() : 0; }
+uint64_t hnswgpu_datamap_dimension(const hnswgpu_datamap* m) { return m ? m->m.dimension() : 0; }
+const char* hnswgpu_datamap_distname(const hnswgpu_datamap* m) { return m ? m->m.distname().c_str() : ""; }
+const char* hnswgpu_datamap_typename(const hnswgpu_datamap* m) { return m ? m->m.type_name().c_str() : ""; }
+uint64_t hnswgpu_datamap_ids(const hnswgpu_datamap* m, uint64_t* out, uint64_t cap) {
+    if (!m) return 0;
+    const auto& ids = m->m.ids_in_file_order();
+    for (uint64_t i = 0; i < ids.size() && i < cap && out; ++i) out[i] = ids[i];
+    return ids.size();
 }
 
 // =========================================================================================

