@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libhnsw_mi355x.so")
 LIB_OVERRIDE = os.environ.get("HNSW_MI355X_LIB")
 
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY, ERR_REF_PANIC = range(9)
-DIST = {"DistL2": 0, "DistCosine": 1, "DistDot": 2, "DistL1": 3}
+DIST = {"DistL2": 0, "DistCosine": 1, "DistDot": 2, "DistL1": 3, "DistHellinger": 4, "DistJeffreys": 5, "DistJensenShannon": 6}
 DIST_NAME = {v: k for k, v in DIST.items()}
 
 
@@ -128,6 +128,8 @@ SYMBOLS = {
     "load_hnswdump_f32_DistL2": (_VP, [_VP]),
     "load_hnswdump_f32_DistCosine": (_VP, [_VP]),
     "load_hnswdump_f32_DistDot": (_VP, [_VP]),
+    "load_hnswdump_f32_DistJensenShannon": (_VP, [_VP]),
+    "load_hnswdump_f32_DistJeffreys": (_VP, [_VP]),
     "init_hnsw_f32": (_VP, [_SZ, _SZ, _SZ, C.c_char_p]),
     "new_hnsw_f32": (_VP, [_SZ, _SZ, _SZ, C.c_char_p, _SZ, _SZ]),
     "insert_f32": (None, [_VP, _SZ, _VP, _SZ]),

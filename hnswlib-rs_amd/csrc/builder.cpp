@@ -9,6 +9,7 @@
 #include <unordered_set>
 
 #include "hnswio.hpp"
+#include "ln_f32.hpp"
 
 namespace hnswgpu {
 
@@ -45,6 +46,27 @@ float dot_ref(const float* a, const float* b, size_t d) {
     float s = 0.f;
     for (size_t i = 0; i < d; ++i) s = s + a[i] * b[i];
     return std::max(1.f - s, 0.f);
+}
+// the distances between probability vectors of the crate's f32 FFI (src/libext.rs:334-345, :491-513); anndists 0.1
+float hellinger_ref(const float* a, const float* b, size_t d) {
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) s = s + std::sqrt(a[i]) * std::sqrt(b[i]);
+    return std::sqrt(std::max(1.f - s, 0.f));
+}
+float jeffreys_ref(const float* a, const float* b, size_t d) {
+    const float M_MIN = 1.0e-30f;
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) s = s + (a[i] - b[i]) * ln_f32(std::max(a[i], M_MIN) / std::max(b[i], M_MIN));
+    return s;
+}
+float jensenshannon_ref(const float* a, const float* b, size_t d) {
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) {
+        const float mean_ab = 0.5f * (a[i] + b[i]);
+        if (a[i] > 0.f) s = s + a[i] * ln_f32(a[i] / mean_ab);
+        if (b[i] > 0.f) s = s + b[i] * ln_f32(b[i] / mean_ab);
+    }
+    return std::sqrt(0.5f * s);
 }
 
 // "fast" mode: 8 vertical accumulators over floor(d/8)*8 elements, horizontal add, scalar tail --
@@ -216,6 +238,12 @@ GraphBuilder::GraphBuilder(const FlatIndex& f, bool fast_arithmetic) {
 }
 
 float GraphBuilder::eval(const float* a, const float* b) const {
+    switch (p_.dist) {  // (no SIMD-order variant of the probability distances)
+        case DIST_HELLINGER: return hellinger_ref(a, b, d_);
+        case DIST_JEFFREYS: return jeffreys_ref(a, b, d_);
+        case DIST_JENSENSHANNON: return jensenshannon_ref(a, b, d_);
+        default: break;
+    }
     if (!p_.fast_arithmetic) {
         switch (p_.dist) {
             case DIST_L2: return l2_ref(a, b, d_);

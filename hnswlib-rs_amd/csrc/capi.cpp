@@ -207,7 +207,7 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
     CAPI_GUARD_BEGIN
     if (!params || !out || (n && !data)) return fail(HNSWGPU_ERR_ARG, "null argument");
     *out = nullptr;
-    if (params->dist < 0 || params->dist > 3) return fail(HNSWGPU_ERR_DISTANCE, "unknown distance");
+    if (params->dist < 0 || params->dist >= DIST_COUNT) return fail(HNSWGPU_ERR_DISTANCE, "unknown distance");
     if (params->max_nb_connection < 2 || params->max_nb_connection > 256)
         return fail(HNSWGPU_ERR_ARG, "error max_nb_connection must be less equal than 256");  // src/hnsw.rs:784-787
     std::unique_ptr<hnswgpu_index> h(new hnswgpu_index());
@@ -555,7 +555,7 @@ int hnswgpu_last_tie_count(const hnswgpu_index* cidx, uint32_t* ties) {
 
 int hnswgpu_eval_distances(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out) {
     CAPI_GUARD_BEGIN
-    if (!a || !b || !out || dist < 0 || dist > 3) return fail(HNSWGPU_ERR_ARG, "bad argument");
+    if (!a || !b || !out || dist < 0 || dist >= DIST_COUNT) return fail(HNSWGPU_ERR_ARG, "bad argument");
     std::string err;
     int rc = eval_distance_matrix_device(dist, a, n, b, n, d, 1, true, out, err);
     if (rc != OK) return fail(rc, err);
@@ -565,7 +565,7 @@ int hnswgpu_eval_distances(int dist, const float* a, const float* b, uint64_t n,
 int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
                                  uint32_t batch, float* out) {
     CAPI_GUARD_BEGIN
-    if (!queries || !rows || !out || dist < 0 || dist > 3) return fail(HNSWGPU_ERR_ARG, "bad argument");
+    if (!queries || !rows || !out || dist < 0 || dist >= DIST_COUNT) return fail(HNSWGPU_ERR_ARG, "bad argument");
     std::string err;
     int rc = eval_distance_matrix_device(dist, queries, nq, rows, n, d, batch, false, out, err);
     if (rc != OK) return fail(rc, err);
@@ -638,6 +638,8 @@ const HnswApif32* load_hnswdump_f32_DistL1(HnswIo* io) { return load_with(io, HN
 const HnswApif32* load_hnswdump_f32_DistL2(HnswIo* io) { return load_with(io, HNSWGPU_DIST_L2); }
 const HnswApif32* load_hnswdump_f32_DistCosine(HnswIo* io) { return load_with(io, HNSWGPU_DIST_COSINE); }
 const HnswApif32* load_hnswdump_f32_DistDot(HnswIo* io) { return load_with(io, HNSWGPU_DIST_DOT); }
+const HnswApif32* load_hnswdump_f32_DistJensenShannon(HnswIo* io) { return load_with(io, HNSWGPU_DIST_JENSENSHANNON); }  // :334-339
+const HnswApif32* load_hnswdump_f32_DistJeffreys(HnswIo* io) { return load_with(io, HNSWGPU_DIST_JEFFREYS); }            // :340-345
 
 static const HnswApif32* new_api(size_t max_nb_conn, size_t ef_const, size_t namelen, const uint8_t* cdistname,
                                  size_t max_elements, size_t max_layer, bool allow_cosine) {

@@ -18,7 +18,8 @@ namespace hnswgpu {
 constexpr unsigned NB_LAYER_MAX = 16;  // src/hnsw.rs:42
 constexpr uint32_t NO_POINT = 0xFFFFFFFFu;
 
-enum Dist : int { DIST_L2 = 0, DIST_COSINE = 1, DIST_DOT = 2, DIST_L1 = 3 };
+enum Dist : int { DIST_L2 = 0, DIST_COSINE = 1, DIST_DOT = 2, DIST_L1 = 3, DIST_HELLINGER = 4, DIST_JEFFREYS = 5, DIST_JENSENSHANNON = 6 };
+constexpr int DIST_COUNT = 7;
 
 inline const char* dist_type_name(int d) {  // type_name::<D>() (src/hnsw.rs:839-841)
     switch (d) {
@@ -26,6 +27,9 @@ inline const char* dist_type_name(int d) {  // type_name::<D>() (src/hnsw.rs:839
         case DIST_COSINE: return "anndists::dist::distances::DistCosine";
         case DIST_DOT: return "anndists::dist::distances::DistDot";
         case DIST_L1: return "anndists::dist::distances::DistL1";
+        case DIST_HELLINGER: return "anndists::dist::distances::DistHellinger";
+        case DIST_JEFFREYS: return "anndists::dist::distances::DistJeffreys";
+        case DIST_JENSENSHANNON: return "anndists::dist::distances::DistJensenShannon";
     }
     return "";
 }
@@ -38,6 +42,9 @@ inline int dist_from_short_name(const std::string& s) {
     if (s == "DistCosine") return DIST_COSINE;
     if (s == "DistDot") return DIST_DOT;
     if (s == "DistL1") return DIST_L1;
+    if (s == "DistHellinger") return DIST_HELLINGER;
+    if (s == "DistJeffreys") return DIST_JEFFREYS;
+    if (s == "DistJensenShannon") return DIST_JENSENSHANNON;
     return -1;
 }
 

@@ -85,6 +85,9 @@ const KernelSet& kernel_set(int metric) {
         case DIST_L2: return kernels_l2();
         case DIST_COSINE: return kernels_cosine();
         case DIST_DOT: return kernels_dot();
+        case DIST_HELLINGER: return kernels_hellinger();
+        case DIST_JEFFREYS: return kernels_jeffreys();
+        case DIST_JENSENSHANNON: return kernels_jensenshannon();
         default: return kernels_l1();
     }
 }

@@ -119,6 +119,9 @@ const KernelSet& kernels_l2();
 const KernelSet& kernels_cosine();
 const KernelSet& kernels_dot();
 const KernelSet& kernels_l1();
+const KernelSet& kernels_hellinger();
+const KernelSet& kernels_jeffreys();
+const KernelSet& kernels_jensenshannon();
 // metric-independent helpers (instantiated once, in the L2 translation unit)
 hipError_t launch_allow_bitmap(hipStream_t stream, const uint64_t* origin_id, uint32_t n, const uint64_t* ids, uint64_t m, uint32_t* allow);
 hipError_t launch_row_sq_norms(hipStream_t stream, const float* vec, double* out, uint32_t n, uint32_t row_stride);

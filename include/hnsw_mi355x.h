@@ -49,7 +49,11 @@ enum {
     HNSWGPU_DIST_L2 = 0,     /* anndists::dist::distances::DistL2     sqrt(sum (a-b)^2)   */
     HNSWGPU_DIST_COSINE = 1, /* ...::DistCosine   1 - a.b/sqrt(|a|^2 |b|^2), f64 sums     */
     HNSWGPU_DIST_DOT = 2,    /* ...::DistDot      1 - a.b (inputs pre-normalised)         */
-    HNSWGPU_DIST_L1 = 3      /* ...::DistL1       sum |a-b|                               */
+    HNSWGPU_DIST_L1 = 3,     /* ...::DistL1       sum |a-b|                               */
+    /* distances between probability vectors (the f32 arms of src/libext.rs:334-345, :491-513)        */
+    HNSWGPU_DIST_HELLINGER = 4,     /* ...::DistHellinger      sqrt(max(1 - sum sqrt(a) sqrt(b), 0))          */
+    HNSWGPU_DIST_JEFFREYS = 5,      /* ...::DistJeffreys       sum (a-b) ln(max(a,1e-30)/max(b,1e-30))        */
+    HNSWGPU_DIST_JENSENSHANNON = 6  /* ...::DistJensenShannon  sqrt(0.5 sum [a ln(a/m) + b ln(b/m)]), m=(a+b)/2 */
 };
 
 typedef struct hnswgpu_index hnswgpu_index; /* opaque: flat host graph + its HBM replica  */
@@ -275,6 +279,8 @@ const HnswApif32* load_hnswdump_f32_DistL1(HnswIo* hnswio);                     
 const HnswApif32* load_hnswdump_f32_DistL2(HnswIo* hnswio);                        /* :316-321 */
 const HnswApif32* load_hnswdump_f32_DistCosine(HnswIo* hnswio);                    /* :322-327 */
 const HnswApif32* load_hnswdump_f32_DistDot(HnswIo* hnswio);                       /* :328-333 */
+const HnswApif32* load_hnswdump_f32_DistJensenShannon(HnswIo* hnswio);             /* :334-339 */
+const HnswApif32* load_hnswdump_f32_DistJeffreys(HnswIo* hnswio);                  /* :340-345 */
 const HnswApif32* init_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namelen,
                                 const uint8_t* cdistname);                         /* :458-523 */
 const HnswApif32* new_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namelen, const uint8_t* cdistname,

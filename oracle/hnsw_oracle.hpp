@@ -32,6 +32,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "ref_logf.hpp"
+
 namespace oracle {
 
 constexpr uint8_t NB_LAYER_MAX = 16;  // src/hnsw.rs:42
@@ -43,7 +45,7 @@ constexpr uint8_t NB_LAYER_MAX = 16;  // src/hnsw.rs:42
 // src/hnsw.rs:952, :1026, :1112, :1146, :1359, :1374, :1506, :1518.
 // Must be compiled with -ffp-contract=off and without -ffast-math (Rust never contracts).
 // ---------------------------------------------------------------------------------------
-enum DistKind : int { DIST_L2 = 0, DIST_COSINE = 1, DIST_DOT = 2, DIST_L1 = 3 };
+enum DistKind : int { DIST_L2 = 0, DIST_COSINE = 1, DIST_DOT = 2, DIST_L1 = 3, DIST_HELLINGER = 4, DIST_JEFFREYS = 5, DIST_JENSENSHANNON = 6 };
 
 // DistL2 on f32: norm = sum_i (a_i-b_i)*(a_i-b_i) accumulated left to right in f32
 // (Iterator::sum), then sqrt.  A true metric (not squared).
@@ -87,8 +89,38 @@ inline float dist_dot(const float* a, const float* b, size_t d) {
     float dot = 1.f - s;
     return std::max(dot, 0.f);
 }
+// The three distances between probability vectors of the crate's f32 FFI (src/libext.rs:334-345, :491-513), recalled like
+// the others from anndists 0.1 src/dist/distances.rs (oracle/PIN.md):
+// DistHellinger: sum_i (sqrt(a_i) * sqrt(b_i)) left to right in f32, then sqrt(max(1 - sum, 0)).
+inline float dist_hellinger(const float* a, const float* b, size_t d) {
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) s = s + std::sqrt(a[i]) * std::sqrt(b[i]);
+    if (!(1.f - s >= -0.000001f)) throw std::runtime_error("DistHellinger: assert 1 - dist >= -1e-6");
+    return std::sqrt(std::max(1.f - s, 0.f));
+}
+// DistJeffreys: sum_i (a_i - b_i) * ln(max(a_i, M_MIN) / max(b_i, M_MIN)), M_MIN = 1e-30, f32 left to right.
+inline float dist_jeffreys(const float* a, const float* b, size_t d) {
+    const float M_MIN = 1.0e-30f;
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) s = s + (a[i] - b[i]) * ref_logf(std::max(a[i], M_MIN) / std::max(b[i], M_MIN));
+    return s;
+}
+// DistJensenShannon: for each i, mean = 0.5 * (a_i + b_i); if a_i > 0: dist += a_i * ln(a_i / mean); if b_i > 0:
+// dist += b_i * ln(b_i / mean) (f32, in that order); result sqrt(0.5 * dist).
+inline float dist_jensenshannon(const float* a, const float* b, size_t d) {
+    float s = 0.f;
+    for (size_t i = 0; i < d; ++i) {
+        const float mean_ab = 0.5f * (a[i] + b[i]);
+        if (a[i] > 0.f) s = s + a[i] * ref_logf(a[i] / mean_ab);
+        if (b[i] > 0.f) s = s + b[i] * ref_logf(b[i] / mean_ab);
+    }
+    return std::sqrt(0.5f * s);
+}
 inline float dist_eval(DistKind k, const float* a, const float* b, size_t d) {
     switch (k) {
+        case DIST_HELLINGER: return dist_hellinger(a, b, d);
+        case DIST_JEFFREYS: return dist_jeffreys(a, b, d);
+        case DIST_JENSENSHANNON: return dist_jensenshannon(a, b, d);
         case DIST_L2: return dist_l2(a, b, d);
         case DIST_COSINE: return dist_cosine(a, b, d);
         case DIST_DOT: return dist_dot(a, b, d);
@@ -102,6 +134,7 @@ inline float dist_eval(DistKind k, const float* a, const float* b, size_t d) {
 // used ONLY to time a SIMD CPU baseline (bench.py); every parity check runs the scalar functions above.
 typedef float v8f_t __attribute__((vector_size(32), aligned(4)));
 __attribute__((target_clones("avx2,fma", "default"))) inline float dist_simd8(DistKind k, const float* a, const float* b, size_t d) {
+    if (k >= DIST_HELLINGER) return dist_eval(k, a, b, d);  // (no SIMD-order variant of the probability distances)
     v8f_t acc = {0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc, acc2 = acc;
     size_t i = 0;
     for (; i + 8 <= d; i += 8) {
@@ -140,6 +173,9 @@ inline const char* dist_type_name(DistKind k) {
         case DIST_COSINE: return "anndists::dist::distances::DistCosine";
         case DIST_DOT: return "anndists::dist::distances::DistDot";
         case DIST_L1: return "anndists::dist::distances::DistL1";
+        case DIST_HELLINGER: return "anndists::dist::distances::DistHellinger";
+        case DIST_JEFFREYS: return "anndists::dist::distances::DistJeffreys";
+        case DIST_JENSENSHANNON: return "anndists::dist::distances::DistJensenShannon";
     }
     return "";
 }

@@ -173,6 +173,20 @@ void orc_dist_matrix(int kind, const float* queries, size_t nq, const float* row
         for (size_t r = 0; r < n; ++r) out[q * n + r] = dist_eval((DistKind)kind, queries + q * d, rows + r * d, d);
 }
 void orc_l2_normalize(float* v, size_t d) { l2_normalize(v, d); }
+// f32::ln restated (ref_logf.hpp) and the host libm's logf, for the exhaustive comparison of the two
+float orc_ref_logf(float x) { return ref_logf(x); }
+uint64_t orc_ref_logf_mismatches(uint32_t first_bits, uint32_t last_bits, uint32_t step) {
+    uint64_t bad = 0;
+    for (uint64_t u = first_bits; u <= last_bits; u += step) {
+        float x, a, b;
+        const uint32_t w = (uint32_t)u;
+        std::memcpy(&x, &w, 4);
+        a = ref_logf(x);
+        b = std::log(x);
+        if (std::memcmp(&a, &b, 4) != 0 && !(a != a && b != b)) ++bad;
+    }
+    return bad;
+}
 
 // Level generator stream (for checking the product builder draws the same levels).
 void orc_levels(size_t max_nb_conn, double scale_factor, size_t maxlevel, size_t n, uint8_t* out) {

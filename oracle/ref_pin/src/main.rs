@@ -11,7 +11,7 @@
 //! the search on it is what gets pinned (ids, f32 distance bits, p_ids, counts, tie order of std's BinaryHeap and the
 //! arithmetic of anndists included).
 //!
-//! The distance type is chosen from the file name prefix: l2_, l1_, cos_, dot_.
+//! The distance type is chosen from the file name prefix: l2_, l1_, cos_, dot_, hell_, jeff_, js_.
 use std::fs;
 use std::io::Write;
 use std::path::Path;
@@ -108,6 +108,12 @@ fn main() -> anyhow::Result<()> {
             run::<DistCosine>(dir, &name)?;
         } else if name.starts_with("dot_") {
             run::<DistDot>(dir, &name)?;
+        } else if name.starts_with("hell_") {
+            run::<DistHellinger>(dir, &name)?;
+        } else if name.starts_with("jeff_") {
+            run::<DistJeffreys>(dir, &name)?;
+        } else if name.starts_with("js_") {
+            run::<DistJensenShannon>(dir, &name)?;
         } else {
             eprintln!("skipping {name}: unknown distance prefix");
         }

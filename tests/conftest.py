@@ -42,6 +42,14 @@ def normalized(n, d, seed):
     return x
 
 
+def probability(n, d, seed):
+    """Probability vectors (non-negative, sum 1 in f32, some exact zeros): the inputs DistHellinger / DistJeffreys /
+    DistJensenShannon are defined on."""
+    x = np.random.default_rng(seed).random((n, d), dtype=np.float32) + np.float32(1e-3)
+    x[:, ::5] = 0.0
+    return np.ascontiguousarray((x / x.sum(1, dtype=np.float32)[:, None]).astype(np.float32))
+
+
 def same_dump_after_reload(before_graph, after_graph, reloads=1):
     """A dump written by an index that was RELOADED from `before` equals `before` byte for byte except for the level
     scale (8 bytes at offset 6 of a v4 graph file): the reference reloads the dumped absolute scale as a factor of

@@ -27,6 +27,9 @@ CASES = {
     "cos_d25": (200, 25, 8, 40, "DistCosine", False, 10, 32, 32),
     "dot_d25": (200, 25, 8, 40, "DistDot", True, 5, 16, 32),
     "l1_d10": (200, 10, 10, 25, "DistL1", False, 10, 20, 32),
+    "hell_d12": (180, 12, 8, 30, "DistHellinger", "prob", 8, 24, 24),
+    "jeff_d12": (180, 12, 8, 30, "DistJeffreys", "prob", 8, 24, 24),
+    "js_d12": (180, 12, 8, 30, "DistJensenShannon", "prob", 8, 24, 24),
 }
 
 
@@ -35,7 +38,12 @@ def main():
         rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
         X = rng.random((n, d), dtype=np.float32)
         Q = rng.random((nq, d), dtype=np.float32)
-        if normalize:
+        if normalize == "prob":   # probability vectors (with exact zeros)
+            for a in (X, Q):
+                a += np.float32(1e-3)
+                a[:, ::5] = 0.0
+                a /= a.sum(1, dtype=np.float32)[:, None]
+        elif normalize:
             for a in (X, Q):
                 for i in range(a.shape[0]):
                     oracle_lib.lib().orc_l2_normalize(a[i].ctypes.data, d)

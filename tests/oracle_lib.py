@@ -13,12 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_hnsw.so")
 
-DIST_L2, DIST_COSINE, DIST_DOT, DIST_L1 = 0, 1, 2, 3
-DIST_BY_NAME = {"DistL2": DIST_L2, "DistCosine": DIST_COSINE, "DistDot": DIST_DOT, "DistL1": DIST_L1}
+DIST_L2, DIST_COSINE, DIST_DOT, DIST_L1, DIST_HELLINGER, DIST_JEFFREYS, DIST_JENSENSHANNON = 0, 1, 2, 3, 4, 5, 6
+DIST_BY_NAME = {"DistL2": DIST_L2, "DistCosine": DIST_COSINE, "DistDot": DIST_DOT, "DistL1": DIST_L1,
+                "DistHellinger": DIST_HELLINGER, "DistJeffreys": DIST_JEFFREYS, "DistJensenShannon": DIST_JENSENSHANNON}
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "hnsw_oracle.hpp", "hnswio_oracle.hpp", "flat_baseline.hpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "hnsw_oracle.hpp", "hnswio_oracle.hpp", "flat_baseline.hpp", "ref_logf.hpp")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
@@ -65,6 +66,10 @@ def lib():
         L.orc_flat_free.argtypes = [C.c_void_p]
         L.orc_flat_parallel_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ref_logf.restype = C.c_float
+        L.orc_ref_logf.argtypes = [C.c_float]
+        L.orc_ref_logf_mismatches.restype = C.c_uint64
+        L.orc_ref_logf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_dist_matrix.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_levels.argtypes = [C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_heap_exercise.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import normalized, uniform
+from conftest import normalized, probability, uniform
 
 
 def dumps_equal(d, a, b):
@@ -24,12 +24,15 @@ CASES = [
     (2000, 10, 32, 128, "DistL2", False, 0.5, False, False),    # tests/equality.rs: modify_level_scale(0.5)
     (1200, 8, 6, 40, "DistL2", False, None, True, False),       # set_extend_candidates(true)
     (1200, 8, 6, 40, "DistL2", False, None, False, True),       # set_keeping_pruned(true)
+    (1200, 12, 8, 40, "DistHellinger", "prob", None, False, False),  # the distances between probability vectors
+    (1200, 12, 8, 40, "DistJeffreys", "prob", None, False, False),
+    (1000, 9, 10, 60, "DistJensenShannon", "prob", None, True, False),
 ]
 
 
 @pytest.mark.parametrize("n,d,m,efc,dist,normalize,scale,extend,keep", CASES)
 def test_serial_insert_matches_oracle(native, oracle, tmp_path, n, d, m, efc, dist, normalize, scale, extend, keep):
-    X = normalized(n, d, n + m) if normalize else uniform(n, d, n + m)
+    X = probability(n, d, n + m) if normalize == "prob" else normalized(n, d, n + m) if normalize else uniform(n, d, n + m)
     o = oracle.OracleHnsw(m, n, 16, efc, dist)
     h = native.Hnsw(m, n, 16, efc, dist)
     if scale is not None:

@@ -8,7 +8,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import normalized, uniform
+from conftest import normalized, probability, uniform
 from test_gpu_parity import assert_same, build_pair
 
 pytestmark = pytest.mark.gpu
@@ -39,6 +39,75 @@ def test_search_distance_routine_sweep(native, oracle, dist):
             assert np.array_equal(got, want), (dist, d, nf, np.argwhere(got != want)[:4].tolist())
     if dist in ("DistL2", "DistL1"):
         assert native.eval_distance_matrix(dist, q, rows, 16)[0, 5] == 0.0
+
+
+@pytest.mark.parametrize("dist", ["DistHellinger", "DistJeffreys", "DistJensenShannon"])
+def test_probability_distances_on_the_device(native, oracle, tmp_path, dist):
+    """The f32 distances between probability vectors of the crate's FFI (src/libext.rs:334-345, :491-513): the search's own
+    routine against the oracle for every dimension residue (sqrt and ln terms per element: the device carries the same
+    restatement of glibc's logf as the oracle), then search parity on a graph, self queries included.  0 ulp."""
+    for d in list(range(1, 70)) + [96, 100, 127, 128, 129, 200, 255, 256, 300]:
+        rows = probability(70, d, 100 + d) if d > 1 else np.ones((70, 1), np.float32)
+        q = probability(3, d, 200 + d) if d > 1 else np.ones((3, 1), np.float32)
+        rows[5] = q[0]
+        want = oracle.dist_matrix(dist, q, rows).view(np.uint32)
+        for nf in ((1, 16, 17, 32, 33, 64) if d in (1, 3, 25, 32, 33, 64, 100, 128) else (17, 64)):
+            got = native.eval_distance_matrix(dist, q, rows, nf).view(np.uint32)
+            assert np.array_equal(got, want), (dist, d, nf, np.argwhere(got != want)[:4].tolist())
+    n, d, m = 3000, 20, 12
+    X = probability(n, d, 7)
+    o = oracle.OracleHnsw(m, n, 16, 80, dist)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "p")
+    h = native.HnswIo(tmp_path, "p").load_hnsw(dist)
+    h.upload(0)
+    Q = probability(300, d, 8)
+    assert_same(h.parallel_search_flat(Q, 10, 48), o.parallel_search(Q, 10, 48))
+    assert_same(h.parallel_search_flat(X[:100], 3, 30), o.parallel_search(X[:100], 3, 30))
+    # GPU-assisted construction, one point per window: the oracle's serial graph byte for byte
+    hb = native.Hnsw(m, n, 16, 80, dist)
+    hb.set_build_options(nthreads=1, gpu_device=0, gpu_window=1)
+    hb.parallel_insert(X[:800])
+    hb.file_dump(tmp_path, "g")
+    o2 = oracle.OracleHnsw(m, n, 16, 80, dist)
+    o2.insert_batch(X[:800])
+    o2.file_dump(tmp_path, "o2")
+    for ext in (".hnsw.graph", ".hnsw.data"):
+        assert open(tmp_path / ("g" + ext), "rb").read() == open(tmp_path / ("o2" + ext), "rb").read()
+
+
+def test_reference_ffi_arms_of_the_probability_distances(native, oracle, tmp_path, monkeypatch):
+    """load_hnswdump_f32_DistJensenShannon / _DistJeffreys (src/libext.rs:334-345) and the DistHellinger / DistJeffreys /
+    DistJensenShannon arms of init_hnsw_f32 (:491-513): build through the FFI, dump, reload, search."""
+    import ctypes as C
+    lib = native.lib()
+    monkeypatch.chdir(tmp_path)
+    X = probability(600, 10, 3)
+    Q = probability(20, 10, 4)
+    for dist, loader in (("DistJensenShannon", lib.load_hnswdump_f32_DistJensenShannon), ("DistJeffreys", lib.load_hnswdump_f32_DistJeffreys),
+                         ("DistHellinger", None)):
+        api = lib.init_hnsw_f32(8, 40, len(dist), dist.encode())
+        assert api
+        for i in range(600):
+            lib.insert_f32(api, 10, X[i].ctypes.data, i)
+        assert lib.file_dump_f32(api, 3, b"ffi") == 1
+        o = oracle.OracleHnsw(8, 600, 16, 40, dist)
+        o.insert_batch(X)
+        o.file_dump(tmp_path, "orc")
+        assert open("ffi.hnsw.graph", "rb").read() == open("orc.hnsw.graph", "rb").read()
+        if loader is not None:
+            lib.drop_hnsw_f32(api)
+            api = loader(lib.get_hnswio(3, b"ffi"))
+            assert api
+            assert not lib.load_hnswdump_f32_DistL2(lib.get_hnswio(3, b"ffi"))   # the dump is not a DistL2 one
+        ref = o.parallel_search(Q, 5, 20)
+        for i in range(20):
+            one = lib.search_neighbours_f32(api, 10, Q[i].ctypes.data, 5, 20)
+            assert one and one.contents.nbgh == ref.counts[i]
+            assert [one.contents.neighbours[j].id for j in range(one.contents.nbgh)] == ref.ids[i, :ref.counts[i]].tolist()
+            assert [one.contents.neighbours[j].d for j in range(one.contents.nbgh)] == ref.dists[i, :ref.counts[i]].tolist()
+            lib.hnswgpu_free_neighbourhood(one)
+        lib.drop_hnsw_f32(api)
 
 
 # ------------------------------------------------------------------------------------------------- filtered search

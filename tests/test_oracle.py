@@ -183,3 +183,52 @@ def test_level_law(oracle):
     assert abs((lv >= 2).mean() - 1 / 256) < 0.001
     lv2 = oracle.levels(16, 200000, scale_factor=0.5)  # modify_level_scale(0.5): P(l>=1) = M^-2
     assert abs((lv2 >= 1).mean() - 1 / 256) < 0.001
+
+
+# ---- the distances between probability vectors (f32 arms of src/libext.rs:334-345, :491-513) and f32::ln
+def test_ref_logf_is_the_hosts_logf(oracle):
+    """f32::ln is the platform libm's logf; oracle/ref_logf.hpp restates glibc's (table + degree-3 polynomial in double).
+    Exhaustively (all 2 139 095 039 positive finite floats, 8 threads, 6 s) the restatement equals glibc 2.35's logf bit for
+    bit, with and without FMA contraction; the suite re-checks a stride of it, every float within 2^20 ulps of 1.0 (where
+    the cancellation is), the subnormals' edge and the special values."""
+    L = oracle.lib()
+    assert L.orc_ref_logf_mismatches(0x00000001, 0x7F7FFFFF, 211) == 0
+    assert L.orc_ref_logf_mismatches(0x3F800000 - (1 << 20), 0x3F800000 + (1 << 20), 1) == 0
+    assert L.orc_ref_logf_mismatches(0x00000001, 0x00900000, 13) == 0
+    assert L.orc_ref_logf(1.0) == 0.0 and L.orc_ref_logf(0.0) == -np.inf and np.isnan(L.orc_ref_logf(-1.0))
+    assert L.orc_ref_logf(np.inf) == np.inf
+
+
+def _prob(n, d, seed):
+    x = np.random.default_rng(seed).random((n, d), dtype=np.float32) + np.float32(1e-3)
+    x[:, ::7] = 0.0                                       # exact zeros are legal in a distribution
+    return (x / x.sum(1, dtype=np.float32)[:, None]).astype(np.float32)
+
+
+def test_probability_distances_follow_the_formulas_step_by_step(oracle):
+    """anndists 0.1 (recalled, oracle/PIN.md): Hellinger sqrt(max(1 - sum sqrt(a) sqrt(b), 0)); Jeffreys
+    sum (a-b) ln(max(a,1e-30)/max(b,1e-30)); JensenShannon sqrt(0.5 sum [a ln(a/m) if a>0] + [b ln(b/m) if b>0]) -- every
+    operation a separate f32 rounding, sums left to right."""
+    f = np.float32
+    ln = lambda v: f(oracle.lib().orc_ref_logf(float(v)))
+    P = _prob(6, 19, 3)
+    for i in range(5):
+        a, b = P[i], P[i + 1]
+        s = f(0)
+        for x, y in zip(a, b):
+            s = f(s + f(np.sqrt(x, dtype=f) * np.sqrt(y, dtype=f)))
+        assert oracle.dist_eval("DistHellinger", a, b) == f(np.sqrt(max(f(f(1) - s), f(0)), dtype=f))
+        s = f(0)
+        for x, y in zip(a, b):
+            s = f(s + f(f(x - y) * ln(f(max(x, f(1e-30)) / max(y, f(1e-30))))))
+        assert oracle.dist_eval("DistJeffreys", a, b) == s
+        s = f(0)
+        for x, y in zip(a, b):
+            m = f(f(0.5) * f(x + y))
+            if x > 0:
+                s = f(s + f(x * ln(f(x / m))))
+            if y > 0:
+                s = f(s + f(y * ln(f(y / m))))
+        assert oracle.dist_eval("DistJensenShannon", a, b) == f(np.sqrt(f(f(0.5) * s), dtype=f))
+    for dist in ("DistHellinger", "DistJeffreys", "DistJensenShannon"):
+        assert abs(oracle.dist_eval(dist, P[0], P[0])) < 4e-4     # d(p, p) = 0 (Hellinger: up to the rounding of sum sqrt(p)^2)

@@ -14,11 +14,11 @@ CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread"
 for m in hnswio builder datamap capi; do
   g++ $CXXFLAGS $2 -c $m.cpp -o $OBJ/$m.o &
 done
-for m in search_kernels_l2 search_kernels_cosine search_kernels_dot search_kernels_l1 search_device; do
+for m in search_kernels_l2 search_kernels_cosine search_kernels_dot search_kernels_l1 search_kernels_hellinger search_kernels_jeffreys search_kernels_jensenshannon search_device; do
   /opt/rocm/bin/hipcc $CXXFLAGS --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt $2 -c $m.hip -o $OBJ/$m.o &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 -o ../lib_$1.so $OBJ/hnswio.o $OBJ/builder.o $OBJ/datamap.o $OBJ/capi.o \
-    $OBJ/search_device.o $OBJ/search_kernels_l2.o $OBJ/search_kernels_cosine.o $OBJ/search_kernels_dot.o $OBJ/search_kernels_l1.o \
+    $OBJ/search_device.o $OBJ/search_kernels_l2.o $OBJ/search_kernels_cosine.o $OBJ/search_kernels_dot.o $OBJ/search_kernels_l1.o $OBJ/search_kernels_hellinger.o $OBJ/search_kernels_jeffreys.o $OBJ/search_kernels_jensenshannon.o \
     -Wl,-rpath,/opt/rocm/lib
 ls -la ../lib_$1.so
