@@ -37,7 +37,7 @@ def build_native(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if force or not fresh():
-                r = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+                r = subprocess.run(["make", "-C", CSRC_DIR, "-j%d" % max(2, os.cpu_count() or 4)], capture_output=True, text=True)
                 if verbose or r.returncode != 0:
                     print(r.stdout)
                     print(r.stderr)

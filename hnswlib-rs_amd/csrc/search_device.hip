@@ -82,13 +82,13 @@ uint32_t ceil_log2(uint64_t x) {
 
 const KernelSet& kernel_set(int metric) {
     switch (metric) {
-        case DIST_L2: return kernels_l2();
-        case DIST_COSINE: return kernels_cosine();
-        case DIST_DOT: return kernels_dot();
-        case DIST_HELLINGER: return kernels_hellinger();
-        case DIST_JEFFREYS: return kernels_jeffreys();
-        case DIST_JENSENSHANNON: return kernels_jensenshannon();
-        default: return kernels_l1();
+        case DIST_L2: return kernels_for<DIST_L2>();
+        case DIST_COSINE: return kernels_for<DIST_COSINE>();
+        case DIST_DOT: return kernels_for<DIST_DOT>();
+        case DIST_HELLINGER: return kernels_for<DIST_HELLINGER>();
+        case DIST_JEFFREYS: return kernels_for<DIST_JEFFREYS>();
+        case DIST_JENSENSHANNON: return kernels_for<DIST_JENSENSHANNON>();
+        default: return kernels_for<DIST_L1>();
     }
 }
 

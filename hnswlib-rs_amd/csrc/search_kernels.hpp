@@ -1,5 +1,5 @@
 // search_kernels.hpp -- plain argument structs and launch entry points shared by the host driver
-// (search_device.hip) and the per-metric kernel translation units (search_kernels_<metric>.hip).
+// (search_device.hip) and the per-metric kernel translation units (search_kernels_tu.hip, compiled per metric and part).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -90,7 +90,8 @@ struct BuildArgs {
     const double* nrm2;
 };
 
-// One translation unit per metric instantiates the kernels (keeps the build parallel and the objects small).
+// Three translation units per metric instantiate the kernels (search_kernels_tu.hip with -DHNSW_THIS_METRIC / -DHNSW_PART:
+// strict search kernels, lean search kernels, everything else) -- keeps the build parallel and the objects small.
 struct KernelSet {
     // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (decisions that depend on the
     // reference's heap order are resolved with literal heaps inside the launch) or lean (such queries are only flagged)
@@ -115,14 +116,16 @@ struct KernelSet {
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
     return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE ? 16u : 0u);
 }
-const KernelSet& kernels_l2();
-const KernelSet& kernels_cosine();
-const KernelSet& kernels_dot();
-const KernelSet& kernels_l1();
-const KernelSet& kernels_hellinger();
-const KernelSet& kernels_jeffreys();
-const KernelSet& kernels_jensenshannon();
-// metric-independent helpers (instantiated once, in the L2 translation unit)
+// kernels_for<METRIC>(): defined in part 2 of that metric's translation units (search_kernels_tu.hip)
+template <int METRIC> const KernelSet& kernels_for();
+template <> const KernelSet& kernels_for<DIST_L2>();
+template <> const KernelSet& kernels_for<DIST_COSINE>();
+template <> const KernelSet& kernels_for<DIST_DOT>();
+template <> const KernelSet& kernels_for<DIST_L1>();
+template <> const KernelSet& kernels_for<DIST_HELLINGER>();
+template <> const KernelSet& kernels_for<DIST_JEFFREYS>();
+template <> const KernelSet& kernels_for<DIST_JENSENSHANNON>();
+// metric-independent helpers (instantiated once, in part 2 of the L2 units)
 hipError_t launch_allow_bitmap(hipStream_t stream, const uint64_t* origin_id, uint32_t n, const uint64_t* ids, uint64_t m, uint32_t* allow);
 hipError_t launch_row_sq_norms(hipStream_t stream, const float* vec, double* out, uint32_t n, uint32_t row_stride);
 hipError_t launch_scatter_lists(hipStream_t stream, const uint32_t* upd, uint32_t n_upd, uint32_t rec_words, const BuildLists& lists);

@@ -14,11 +14,17 @@ CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread"
 for m in hnswio builder datamap capi; do
   g++ $CXXFLAGS $2 -c $m.cpp -o $OBJ/$m.o &
 done
-for m in search_kernels_l2 search_kernels_cosine search_kernels_dot search_kernels_l1 search_kernels_hellinger search_kernels_jeffreys search_kernels_jensenshannon search_device; do
-  /opt/rocm/bin/hipcc $CXXFLAGS --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt $2 -c $m.hip -o $OBJ/$m.o &
+/opt/rocm/bin/hipcc $CXXFLAGS --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt $2 -c search_device.hip -o $OBJ/search_device.o &
+KOBJS=""
+for m in 0 1 2 3 4 5 6; do
+  for p in 0 1 2; do
+    /opt/rocm/bin/hipcc $CXXFLAGS --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt $2 -DHNSW_THIS_METRIC=$m -DHNSW_PART=$p \
+        -c search_kernels_tu.hip -o $OBJ/sk_${m}_$p.o &
+    KOBJS="$KOBJS $OBJ/sk_${m}_$p.o"
+  done
+  wait   # three units of one metric at a time next to the host objects: bounded memory
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 -o ../lib_$1.so $OBJ/hnswio.o $OBJ/builder.o $OBJ/datamap.o $OBJ/capi.o \
-    $OBJ/search_device.o $OBJ/search_kernels_l2.o $OBJ/search_kernels_cosine.o $OBJ/search_kernels_dot.o $OBJ/search_kernels_l1.o $OBJ/search_kernels_hellinger.o $OBJ/search_kernels_jeffreys.o $OBJ/search_kernels_jensenshannon.o \
-    -Wl,-rpath,/opt/rocm/lib
+    $OBJ/search_device.o $KOBJS -Wl,-rpath,/opt/rocm/lib
 ls -la ../lib_$1.so
