@@ -499,10 +499,13 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (strict_kernel) {  // top levels of the literal candidate heap, for the few queries that need it
             a.cand_lds = 512;
             lds += (size_t)a.cand_lds * sizeof(hent_t);
+        } else if (slots == 1) {
+            lds += 128 * sizeof(hent_t);  // merge_list's scatter buffer (the strict kernel borrows the heap's LDS for it)
         }
         int per_cu = 0;
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));
         if (per_cu < 1) per_cu = 1;
+        if (const char* e = std::getenv("HNSWGPU_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // tuning hook
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
         a.queries = w.qpad.as<float>();
         a.qlist = qlist;
