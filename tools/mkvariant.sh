@@ -15,7 +15,7 @@ mkdir -p $OBJ
 CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread"
 HIPFLAGS="--offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt"
 if [ -n "${ONLY_METRICS:-}" ]; then
-  make -j8 >/dev/null   # the product's objects, up to date
+  flock .build.lock make -j8 >/dev/null   # the product's objects, up to date (one make at a time)
   for f in hnswio builder datamap capi search_device; do cp $f.o $OBJ/$f.o; done
   for m in 0 1 2 3 4 5 6; do for p in 0 1 2; do cp sk_${m}_$p.o $OBJ/sk_${m}_$p.o; done; done
   METRICS="$ONLY_METRICS"
