@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--host-build", action="store_true", help="build the graph on the host cores only (default: GPU-assisted "
                     "construction: the insertions' searches on the device, window by window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the two-caller-threads reference measurement")
     ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
     ap.add_argument("--dump-stats", default="", help="write the per-query kernel stats of the last step to this .npy")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -352,6 +353,45 @@ def main():
         step(0)
         fast_qps = nq_total * args.steps / timed(args.steps)
         lib.hnswgpu_set_strict_ties(index.handle, 1)
+    # for reference: the same steps issued by two caller threads (each its own stream and output buffers; the library
+    # serves concurrent calls from a workspace pool).  One launch ends with its longest search while the machine
+    # drains; a second batch in flight fills that tail.  Not `value`: one caller, one batch at a time.
+    two_callers_qps = None
+    if world == 1 and not args.no_concurrent:
+        import threading
+        lanes = []
+        for _ in range(2):
+            lanes.append({"stream": torch.cuda.Stream(dev),
+                          "ids": torch.zeros_like(out_ids), "dists": torch.zeros_like(out_dists), "layer": torch.zeros_like(out_layer),
+                          "rank": torch.zeros_like(out_rank), "counts": torch.zeros_like(out_counts), "stats": torch.zeros_like(stats)})
+        errors = []
+
+        def caller(li, nsteps):
+            ln = lanes[li]
+            for i in range(li, nsteps, 2):
+                rc = lib.hnswgpu_search_batch_device(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, ln["ids"].data_ptr(),
+                                                     ln["dists"].data_ptr(), ln["layer"].data_ptr(), ln["rank"].data_ptr(),
+                                                     ln["counts"].data_ptr(), ln["stats"].data_ptr(), ln["stream"].cuda_stream)
+                if rc != 0:
+                    errors.append(H._native.last_error())
+                    return
+
+        def run_callers(nsteps):
+            fence()
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=caller, args=(li, nsteps)) for li in range(2)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            fence()
+            return time.perf_counter() - t0
+
+        run_callers(2 * max(1, args.warmup))
+        el2 = run_callers(args.steps)
+        if errors:
+            raise RuntimeError(errors[0])
+        two_callers_qps = nq_total * args.steps / el2
     step(0)   # leave the strict answers of batch 0 in the output buffers for the recall / parity checks below
     fence()
 
@@ -450,6 +490,7 @@ def main():
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
             "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},
+            "two_caller_threads_queries_per_s": None if two_callers_qps is None else round(two_callers_qps, 1),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_vs_oracle": parity,
