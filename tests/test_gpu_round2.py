@@ -363,3 +363,29 @@ def test_gpu_assisted_construction_windows_build_a_graph_as_good(native, oracle,
             assert_same(res, o.parallel_search(Q, k, ef))
     assert recalls["gpu"] > recalls["host"] - 0.01, recalls
     assert recalls["gpu"] > 0.9, recalls
+
+
+# ------------------------------------------------------------------------------------------------- result-set sizes
+@pytest.mark.parametrize("kind", ["uniform", "ties"])
+def test_result_set_sizes_around_the_slot_switches(native, oracle, tmp_path, kind):
+    """ef = max(ef, k) around every size at which the kernel changes shape: 63 / 64 / 65 (one or two entries of
+    return_points per lane; at exactly 64 every lane holds one and the whole-list accept rule has no spare lane), 127 / 128 /
+    129, 255 / 256 / 257, k = ef, and an index smaller than ef.  `ties`: small-integer coordinates, so that equal
+    distances sit on both sides of the cut at ef again and again (the whole-list accept rule must hand those lists
+    back to the one-at-a-time path) -- src/hnsw.rs:1028-1053."""
+    from test_gpu_parity import _tie_heavy
+    n, d = 2500, 8
+    X = uniform(n, d, 5) if kind == "uniform" else _tie_heavy("grid", n, d, 5)
+    o = oracle.OracleHnsw(10, n, 16, 60, "DistL2")
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "sizes")
+    h = native.HnswIo(tmp_path, "sizes").load_hnsw("DistL2")
+    h.upload(0)
+    Q = uniform(120, d, 6) if kind == "uniform" else _tie_heavy("grid", 120, d, 6)
+    most_ties = 0
+    for k, ef in ((10, 63), (10, 64), (10, 65), (64, 64), (64, 10), (10, 127), (10, 128), (10, 129), (128, 128), (10, 255),
+                  (10, 256), (10, 257), (3, 2), (1, 1)):
+        assert_same(h.parallel_search_flat(Q, k, ef), o.parallel_search(Q, k, ef))
+        most_ties = max(most_ties, h.last_tie_count())
+    if kind == "ties":
+        assert most_ties > 10  # the data really puts equal distances at decisive places
