@@ -389,3 +389,20 @@ def test_result_set_sizes_around_the_slot_switches(native, oracle, tmp_path, kin
         most_ties = max(most_ties, h.last_tie_count())
     if kind == "ties":
         assert most_ties > 10  # the data really puts equal distances at decisive places
+
+
+def test_one_call_with_100k_queries_and_tiny_dimensions(native, oracle, tmp_path):
+    """BASELINE config 4 hands 100 000 queries to the path; here they go through ONE call on one device (the persistent
+    grid takes them from its work counter), and every answer is compared.  Then d = 1 and d = 2: one padded chunk per
+    row, most distances equal or nearly so."""
+    X, o, h = build_pair(native, oracle, tmp_path, 5000, 16, 12, 80, "DistL2", seed=21, tag="big")
+    Q = uniform(100_000, 16, 22)
+    res = h.parallel_search_flat(Q, 10, 32)
+    ref = o.parallel_search(Q, 10, 32)
+    assert np.array_equal(res.counts, ref.counts)
+    assert np.array_equal(res.ids, ref.ids)
+    assert np.array_equal(res.dists.view(np.uint32), ref.dists.view(np.uint32))
+    for d in (1, 2):
+        X, o, h = build_pair(native, oracle, tmp_path, 1500, d, 8, 40, "DistL2", seed=30 + d, tag=f"d{d}")
+        Q = uniform(200, d, 31)
+        assert_same(h.parallel_search_flat(Q, 10, 40), o.parallel_search(Q, 10, 40))
