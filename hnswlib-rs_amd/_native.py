@@ -132,6 +132,7 @@ SYMBOLS = {
     "load_hnswdump_f32_DistJeffreys": (_VP, [_VP]),
     "init_hnsw_f32": (_VP, [_SZ, _SZ, _SZ, C.c_char_p]),
     "new_hnsw_f32": (_VP, [_SZ, _SZ, _SZ, C.c_char_p, _SZ, _SZ]),
+    "init_hnsw_ptrdist_f32": (_VP, [_SZ, _SZ, _VP]),
     "insert_f32": (None, [_VP, _SZ, _VP, _SZ]),
     "parallel_insert_f32": (None, [_VP, _SZ, _SZ, _VP, _VP]),
     "search_neighbours_f32": (C.POINTER(Neighbourhood_api), [_VP, _SZ, _VP, _SZ, _SZ]),

@@ -676,6 +676,13 @@ const HnswApif32* new_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namel
                                size_t max_elements, size_t max_layer) {
     return new_api(max_nb_conn, ef_const, namelen, cdistname, max_elements, max_layer, false);
 }
+const HnswApif32* init_hnsw_ptrdist_f32(size_t, size_t, hnsw_dist_fn_f32) {
+    // src/libext.rs:643-655 builds Hnsw<f32, DistCFFI<f32>> around a host function pointer: nothing the device can call
+    fail(HNSWGPU_ERR_DISTANCE, "init_hnsw_ptrdist_f32: a host distance callback cannot run on the device and there is no CPU "
+                               "search path; use a named distance (DistL2, DistL1, DistCosine, DistDot, DistHellinger, "
+                               "DistJeffreys, DistJensenShannon)");
+    return nullptr;
+}
 
 // The reference's insert_f32 / parallel_insert_f32 return nothing (:661-723).  They work on every handle, reloaded ones
 // included; a failure (dimension mismatch, ...) leaves the index unchanged and is readable through hnswgpu_last_error().

@@ -285,6 +285,12 @@ const HnswApif32* init_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t name
                                 const uint8_t* cdistname);                         /* :458-523 */
 const HnswApif32* new_hnsw_f32(size_t max_nb_conn, size_t ef_const, size_t namelen, const uint8_t* cdistname,
                                size_t max_elements, size_t max_layer);             /* :532-580 */
+/* The crate's init_hnsw_ptrdist_f32 takes a HOST function pointer as the distance (DistCFFI<f32>).  A host callback
+ * cannot be evaluated by the device, and this library has no CPU search path by design: the symbol exists so that a host
+ * linking the crate's C interface resolves, it always returns NULL and sets HNSWGPU_ERR_DISTANCE (hnswgpu_last_error()
+ * says why).  Use one of the named distances. */
+typedef float (*hnsw_dist_fn_f32)(const float* a, const float* b, unsigned long long len);
+const HnswApif32* init_hnsw_ptrdist_f32(size_t max_nb_conn, size_t ef_const, hnsw_dist_fn_f32 c_func);  /* :643-655 */
 void insert_f32(HnswApif32* hnsw_api, size_t len, const float* data, size_t id);   /* :661-678 */
 void parallel_insert_f32(HnswApif32* hnsw_api, size_t nb_vec, size_t vec_len, const float** datas,
                          const size_t* ids);                                       /* :683-723 */

@@ -123,3 +123,12 @@ def test_plain_c_caller_of_the_reference_style_symbols(native, tmp_path):
     r = subprocess.run([exe, str(work)], capture_output=True, text=True)
     assert r.returncode == 0, f"exit {r.returncode}: {r.stdout} {r.stderr}"
     assert (work / "c_caller.hnsw.graph").exists() and (work / "c_caller.hnsw.data").exists()
+
+
+def test_host_distance_callback_is_refused_with_a_reason(native):
+    """init_hnsw_ptrdist_f32 (src/libext.rs:643-655) cannot be served by a device path: NULL + a message, never a crash."""
+    import ctypes as C
+    lib = native.lib()
+    cb = C.CFUNCTYPE(C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_ulonglong)(lambda a, b, n: 0.0)
+    assert not lib.init_hnsw_ptrdist_f32(16, 200, C.cast(cb, C.c_void_p))
+    assert "callback" in native._native.last_error()
