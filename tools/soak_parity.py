@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Soak test at full size: many fresh query batches against the graph a bench run left in its cache, every answer of the
+strict path compared with the oracle (ids, f32 distance bits, p_ids, counts).  Run after `python bench.py --config C`
+on the same box:   python tools/soak_parity.py --config sift1m --batches 10
+(The oracle is the checker here, like in tests/ -- this is a test driver, not a product path.)"""
+import argparse
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402  (CONFIGS, synth)
+import hnsw_rs_amd as H  # noqa: E402
+import oracle_lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="sift1m", choices=sorted(bench.CONFIGS))
+ap.add_argument("--batches", type=int, default=8)
+ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
+args = ap.parse_args()
+cfg = bench.CONFIGS[args.config]
+dumps = sorted(glob.glob(os.path.join(args.cache_dir, f"bench_{args.config}_*.done")))
+if not dumps:
+    sys.exit(f"no cached graph for {args.config} in {args.cache_dir}: run bench.py --config {args.config} first")
+base = os.path.basename(dumps[-1])[:-5]
+h = H.HnswIo(args.cache_dir, base).load_hnsw(cfg["dist"])
+h.upload(0)
+o = oracle_lib.OracleHnsw.load(args.cache_dir, base, cfg["dist"])
+k, ef, d, nq = cfg["k"], cfg["ef"], cfg["d"], cfg["nq"]
+bad = checked = ties = 0
+t0 = time.time()
+for b in range(args.batches):
+    Q = bench.synth(nq, d, 0xABCD0000 + b, "clustered" if b % 2 == 0 else "uniform")
+    if cfg["dist"] == "DistDot":
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    res = h.parallel_search_flat(Q, k, ef)
+    ties += h.last_tie_count()
+    ref = o.parallel_search(Q, k, ef)
+    ok = (np.all(res.ids == ref.ids, axis=1) & np.all(res.dists.view(np.uint32) == ref.dists.view(np.uint32), axis=1)
+          & np.all(res.layers == ref.layers, axis=1) & np.all(res.ranks == ref.ranks, axis=1) & (res.counts == ref.counts))
+    bad += int((~ok).sum())
+    checked += nq
+print(f"{args.config}: {checked} queries in {args.batches} batches ({time.time() - t0:.1f} s), {ties} answered through the literal heaps, "
+      f"{bad} differ from the oracle")
+sys.exit(1 if bad else 0)
