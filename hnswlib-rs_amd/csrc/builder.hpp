@@ -100,6 +100,7 @@ private:
                            unsigned layer, Tls& t, std::vector<Edge>& out);
     void reverse_update(uint32_t id, Tls& t);
     void read_list(uint32_t id, unsigned layer, std::vector<Edge>& out) const;
+    std::vector<Edge>& wlist(Node& nd, unsigned layer) const;
 
     BuildParams p_;
     uint64_t n_ = 0, d_ = 0;

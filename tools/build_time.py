@@ -5,7 +5,7 @@ import numpy as np
 import bench
 import hnsw_rs_amd as H
 X = bench.synth(1_000_000, 128, 0x5EED0001, "clustered")
-for fast, nth in ((False, 0), (True, 0), (False, 32), (False, 24)):
+for fast, nth in ((False, 32), (False, 64), (False, 128), (False, 256), (True, 64)):
     t0 = time.time()
     hb = H.Hnsw(16, len(X), 16, 200, "DistL2")
     hb.set_build_options(nthreads=nth, gpu_device=0, gpu_window=0, fast_arithmetic=fast)
