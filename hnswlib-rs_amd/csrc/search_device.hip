@@ -469,7 +469,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         HIP_TRY(kernel_set(dist_).launch_estimate(dgrid, stream, v_, da));
         HIP_TRY(kernel_set(dist_).launch_order(stream, w.predist.as<float>(), (uint32_t)nq, w.order.as<uint32_t>()));
     }
-    uint32_t launches = 0;
+    uint32_t launches = 0, stop_recorded_after = ~0u;
     uint32_t work = (uint32_t)nq;
     uint32_t n_flagged = 0, n_literal = 0;
     const uint32_t* qlist = scheduled ? w.order.as<uint32_t>() : nullptr;
@@ -551,6 +551,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         ++launches;
         volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);  // pinned: a true asynchronous copy
         HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 24, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(w.ev_stop, stream));  // the end of the call unless another launch follows (the usual case: one wait)
+        stop_recorded_after = launches;
         HIP_TRY(wait_stream(stream));
         n_flagged = ctrl[4];     // not resolved in the launch (cumulative over relaunches)
         n_literal += ctrl[5];    // resolved with the literal heaps inside the launch
@@ -585,8 +587,10 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (rc != OK) return rc;
         ++launches;
     }
-    HIP_TRY(hipEventRecord(w.ev_stop, stream));
-    HIP_TRY(wait_event(w.ev_stop));
+    if (stop_recorded_after != launches) {  // the literal kernel ran after the last recorded end
+        HIP_TRY(hipEventRecord(w.ev_stop, stream));
+        HIP_TRY(wait_event(w.ev_stop));
+    }
     float ms = 0.f, ms_main = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, w.ev_start, w.ev_stop));
     HIP_TRY(hipEventElapsedTime(&ms_main, w.ev_ks, w.ev_ke));  // first launch of the search kernel alone
