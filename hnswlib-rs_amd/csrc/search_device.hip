@@ -499,8 +499,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (strict_kernel) {  // top levels of the literal candidate heap, for the few queries that need it
             a.cand_lds = 512;
             lds += (size_t)a.cand_lds * sizeof(hent_t);
-        } else if (slots == 1) {
-            lds += 128 * sizeof(hent_t);  // merge_list's scatter buffer (the strict kernel borrows the heap's LDS for it)
+        } else if (slots <= HNSW_MERGE_LEAN_SMAX) {
+            lds += ((size_t)slots * 64 + 64) * sizeof(hent_t);  // merge_list's scatter buffer (the strict kernel borrows the heap's LDS for it)
         }
         int per_cu = 0;
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));

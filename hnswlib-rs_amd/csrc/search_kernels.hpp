@@ -112,6 +112,14 @@ struct KernelSet {
     hipError_t (*launch_build_search)(int slots, uint32_t grid, size_t lds, hipStream_t stream, const BuildArgs& a);
     hipError_t (*build_occupancy)(int slots, size_t lds, int* per_cu);
 };
+// merge_list (the accept rule for a whole neighbour list at once) is used up to this many result slots per lane: in strict
+// kernels it scatters through the LDS of the literal candidate heap's top, a lean launch gets 64 S + 64 entries for it
+#ifndef HNSW_MERGE_SMAX
+#define HNSW_MERGE_SMAX 4
+#endif
+#ifndef HNSW_MERGE_LEAN_SMAX
+#define HNSW_MERGE_LEAN_SMAX 2
+#endif
 // LDS in front of the id buffer: the query row; DistCosine keeps the query's squared norm (f64) behind it
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
     return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE ? 16u : 0u);
