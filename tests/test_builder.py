@@ -83,6 +83,32 @@ def test_parallel_insert_gives_a_valid_graph(native, oracle, tmp_path):
     assert rec > 0.9
 
 
+def test_parallel_insert_with_lock_free_readers_keeps_edges_whole(native, oracle, tmp_path):
+    """The builder's searches copy neighbour lists under a sequence counter, without a lock, while other threads rewrite
+    them: an edge must never come out torn.  Many more threads than cores, then every sampled (neighbour, distance) pair
+    is checked against the vectors."""
+    n, d, m = 8000, 8, 8
+    X = uniform(n, d, 12)
+    for nthreads in (32, 13):
+        h = native.Hnsw(m, n, 16, 60, "DistL2")
+        h.set_build_options(nthreads=nthreads)
+        h.parallel_insert(X)
+        assert h.get_nb_point() == n
+        checked = 0
+        lv = oracle.levels(m, n)  # ranks inside a layer follow the input order
+        for layer in range(2):
+            members = np.nonzero(lv == layer)[0]
+            for rank in range(0, h.get_layer_nb_point(layer), 11):
+                ids, _, _, dists = h.get_neighbours(layer, rank, 0)
+                ids = ids.astype(np.int64)
+                me = int(members[rank])
+                assert np.all(ids < n) and me not in set(ids.tolist())
+                true = np.sqrt(((X[ids].astype(np.float64) - X[me].astype(np.float64)) ** 2).sum(-1))
+                assert np.allclose(dists, true, rtol=1e-5, atol=1e-6)
+                checked += len(ids)
+        assert checked > 1000
+
+
 def test_fast_arithmetic_build_is_searchable(native, oracle, tmp_path):
     X = uniform(3000, 32, 4)
     h = native.Hnsw(16, 3000, 16, 100, "DistL2")
