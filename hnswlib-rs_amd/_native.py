@@ -112,6 +112,8 @@ SYMBOLS = {
     "hnswgpu_device_count": (_I, []),
     "hnswgpu_search_batch": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
     "hnswgpu_search_batch_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hnswgpu_search_batch_device_begin": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hnswgpu_search_batch_end": (_I, [_VP]),
     "hnswgpu_search_batch_filtered": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hnswgpu_search_batch_sharded": (_I, [_VP, _VP, _I, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
     "hnswgpu_search_batch_filtered_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP,

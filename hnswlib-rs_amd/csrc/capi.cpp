@@ -495,6 +495,42 @@ int hnswgpu_search_batch_device(const hnswgpu_index* cidx, const float* d_querie
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
 }
 
+// begin / end: the blocking call on a worker thread of its own (searches on one handle may run concurrently, each with
+// a private workspace), so the launch path is the one every other entry point uses
+struct hnswgpu_ticket {
+    std::thread worker;
+    int status = HNSWGPU_OK;
+    std::string error;
+};
+int hnswgpu_search_batch_device_begin(const hnswgpu_index* cidx, const float* d_queries, uint64_t nq, uint64_t d, uint64_t k,
+                                      uint64_t ef, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
+                                      int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* d_stats, void* stream,
+                                      hnswgpu_ticket** ticket) {
+    CAPI_GUARD_BEGIN
+    if (!ticket) return fail(HNSWGPU_ERR_ARG, "null ticket");
+    *ticket = nullptr;
+    if (!cidx) return fail(HNSWGPU_ERR_ARG, "null index");
+    std::unique_ptr<hnswgpu_ticket> t(new hnswgpu_ticket());
+    hnswgpu_ticket* raw = t.get();
+    raw->worker = std::thread([=]() {
+        raw->status = hnswgpu_search_batch_device(cidx, d_queries, nq, d, k, ef, d_out_ids, d_out_dists, d_out_layer, d_out_rank,
+                                                  d_out_counts, d_stats, stream);
+        if (raw->status != HNSWGPU_OK) raw->error = hnswgpu_last_error();  // this thread's message, handed to the ticket
+    });
+    *ticket = t.release();
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+int hnswgpu_search_batch_end(hnswgpu_ticket* ticket) {
+    CAPI_GUARD_BEGIN
+    if (!ticket) return fail(HNSWGPU_ERR_ARG, "null ticket");
+    std::unique_ptr<hnswgpu_ticket> t(ticket);
+    if (t->worker.joinable()) t->worker.join();
+    if (t->status != HNSWGPU_OK) return fail(t->status, t->error);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
 int hnswgpu_search_batch_filtered_device(const hnswgpu_index* cidx, const float* d_queries, uint64_t nq, uint64_t d, uint64_t k,
                                          uint64_t ef, const uint64_t* d_allowed_ids, uint64_t n_allowed, uint64_t* d_out_ids,
                                          float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,

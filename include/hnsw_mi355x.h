@@ -212,6 +212,18 @@ int hnswgpu_search_batch_filtered_device(const hnswgpu_index* idx, const float* 
                                          uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
                                          int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* d_stats, void* stream,
                                          uint32_t* n_panics);
+/* The same call, not waited for: hnswgpu_search_batch_device_begin returns at once with a ticket (a worker thread of
+ * the library issues the launches on `stream` and waits for them), hnswgpu_search_batch_end waits for that call, returns
+ * its status (its message is then hnswgpu_last_error() of the caller's thread) and releases the ticket.  Two batches in
+ * flight from one host thread keep the device full while a launch drains towards its longest search (DESIGN.md
+ * section 8).  Every ticket must be ended exactly once; the buffers and the index must stay alive until then; give
+ * concurrent tickets different output buffers (and, to let them overlap on the device, different streams).          */
+typedef struct hnswgpu_ticket hnswgpu_ticket;
+int hnswgpu_search_batch_device_begin(const hnswgpu_index* idx, const float* d_queries, uint64_t nq, uint64_t d,
+                                      uint64_t k, uint64_t ef, uint64_t* d_out_ids, float* d_out_dists,
+                                      uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
+                                      uint32_t* d_stats, void* stream, hnswgpu_ticket** ticket);
+int hnswgpu_search_batch_end(hnswgpu_ticket* ticket);
 /* Concurrency: the search entry points may be called from several host threads on ONE handle at the same time (the
  * reference's search is `&self`); every call takes a private workspace.  Calls that change the index (insert, upload)
  * wait for running searches.                                                                                       */

@@ -406,3 +406,61 @@ def test_one_call_with_100k_queries_and_tiny_dimensions(native, oracle, tmp_path
         X, o, h = build_pair(native, oracle, tmp_path, 1500, d, 8, 40, "DistL2", seed=30 + d, tag=f"d{d}")
         Q = uniform(200, d, 31)
         assert_same(h.parallel_search_flat(Q, 10, 40), o.parallel_search(Q, 10, 40))
+
+
+def test_begin_end_keeps_two_batches_in_flight_from_one_thread(native, oracle, tmp_path):
+    """hnswgpu_search_batch_device_begin / hnswgpu_search_batch_end: the device-buffer call, not waited for.  Three tickets
+    in flight from this one thread (own streams and output buffers), ended in another order than begun; then a ticket
+    whose call fails (wrong dimension): its status and message arrive at hnswgpu_search_batch_end.
+    Device buffers and streams come straight from the HIP runtime the library itself is linked to."""
+    import ctypes as C
+    X, o, h = build_pair(native, oracle, tmp_path, 5000, 24, 12, 80, "DistL2", seed=91)
+    lib = native.lib()
+    hip = C.CDLL("libamdhip64.so")
+    H2D, D2H = 1, 2
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        return p
+
+    def fetch(p, shape, dtype):
+        a = np.zeros(shape, dtype)
+        assert hip.hipMemcpy(a.ctypes.data_as(C.c_void_p), p, C.c_size_t(a.nbytes), D2H) == 0
+        return a
+
+    k, ef = 8, 64
+    batches = [uniform(400 + 50 * t, 24, 90 + t) for t in range(3)]
+    refs = [o.parallel_search(b, k, ef) for b in batches]
+    bufs, tickets = [], []
+    for b in batches:
+        nq = len(b)
+        q = dmalloc(b.nbytes)
+        assert hip.hipMemcpy(q, b.ctypes.data_as(C.c_void_p), C.c_size_t(b.nbytes), H2D) == 0
+        st = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(st)) == 0
+        outs = dict(ids=dmalloc(nq * k * 8), d=dmalloc(nq * k * 4), layer=dmalloc(nq * k), rank=dmalloc(nq * k * 4), cnt=dmalloc(nq * 4),
+                    stats=dmalloc(nq * 32))
+        t = C.c_void_p()
+        rc = lib.hnswgpu_search_batch_device_begin(h.handle, q, nq, 24, k, ef, outs["ids"], outs["d"], outs["layer"], outs["rank"], outs["cnt"],
+                                                   outs["stats"], st, C.byref(t))
+        assert rc == 0 and t.value
+        bufs.append((q, st, outs, nq))
+        tickets.append(t)
+    for i in (2, 0, 1):
+        assert lib.hnswgpu_search_batch_end(tickets[i]) == 0
+    for (q, st, outs, nq), ref in zip(bufs, refs):
+        assert np.array_equal(fetch(outs["cnt"], (nq,), np.uint32), ref.counts.astype(np.uint32))
+        assert np.array_equal(fetch(outs["ids"], (nq, k), np.uint64), ref.ids.astype(np.uint64))
+        assert np.array_equal(fetch(outs["d"], (nq, k), np.uint32), ref.dists.view(np.uint32))
+    # a failing call: the error travels with the ticket
+    q, st, outs, nq = bufs[0]
+    t = C.c_void_p()
+    assert lib.hnswgpu_search_batch_device_begin(h.handle, q, 10, 23, k, ef, outs["ids"], outs["d"], outs["layer"], outs["rank"], outs["cnt"],
+                                                 outs["stats"], st, C.byref(t)) == 0
+    assert lib.hnswgpu_search_batch_end(t) != 0
+    assert "dimension" in native._native.last_error()
+    for q, st, outs, nq in bufs:
+        for p in [q] + list(outs.values()):
+            hip.hipFree(p)
+        hip.hipStreamDestroy(st)
