@@ -496,11 +496,14 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         a.idbits = idbits;
         const KernelSet& ks = kernel_set(dist_);
         const bool strict_kernel = strict_ties && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
-        if (strict_kernel) {  // top levels of the literal candidate heap, for the few queries that need it
-            a.cand_lds = 512;
+        if (slots <= (strict_kernel ? HNSW_MERGE_SMAX : HNSW_MERGE_LEAN_SMAX)) {  // merge_list's scatter buffer
+            a.merge_entries = (uint32_t)slots * 64u + 64u;
+            lds += (size_t)a.merge_entries * sizeof(hent_t);
+        }
+        if (strict_kernel) {  // top levels of the (lazy) literal candidate heap, for the few pops that need it
+            a.cand_lds = 256;
+            if (const char* e = std::getenv("HNSWGPU_CAND_LDS")) a.cand_lds = (uint32_t)std::max(0, std::min(4096, std::atoi(e)));  // tuning hook
             lds += (size_t)a.cand_lds * sizeof(hent_t);
-        } else if (slots <= HNSW_MERGE_LEAN_SMAX) {
-            lds += ((size_t)slots * 64 + 64) * sizeof(hent_t);  // merge_list's scatter buffer (the strict kernel borrows the heap's LDS for it)
         }
         int per_cu = 0;
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));

@@ -38,7 +38,8 @@ struct SearchArgs {
                             // (count at overflow_count + 3)
     hent_t* cand_scratch;   // strict ties: [gridDim.x][cand_cap] literal candidate heap beyond its LDS part
     uint32_t cand_cap;
-    uint32_t cand_lds;      // strict ties: entries of the literal candidate heap kept in LDS (behind the visited table)
+    uint32_t cand_lds;      // strict ties: entries of the literal candidate heap kept in LDS (behind merge_list's buffer)
+    uint32_t merge_entries; // LDS entries of merge_list's scatter buffer behind the visited table (64 S + 64, or 0: not used)
     uint32_t exact_first;   // strict ties, test hook: literal candidate heap from the first pop on
     hent_t* oplog;          // strict ties: [gridDim.x][oplog_cap] per-workgroup log of heap operations
     uint32_t oplog_cap;
@@ -112,8 +113,8 @@ struct KernelSet {
     hipError_t (*launch_build_search)(int slots, uint32_t grid, size_t lds, hipStream_t stream, const BuildArgs& a);
     hipError_t (*build_occupancy)(int slots, size_t lds, int* per_cu);
 };
-// merge_list (the accept rule for a whole neighbour list at once) is used up to this many result slots per lane: in strict
-// kernels it scatters through the LDS of the literal candidate heap's top, a lean launch gets 64 S + 64 entries for it
+// merge_list (the accept rule for a whole neighbour list at once) is used up to this many result slots per lane; the launch
+// gets 64 S + 64 LDS entries for its scatter
 #ifndef HNSW_MERGE_SMAX
 #define HNSW_MERGE_SMAX 4
 #endif
