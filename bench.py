@@ -177,6 +177,31 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     return cpu_baseline, parity
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: this process becomes the launcher -- one rank per GPU through
+    torch.distributed.run on this node -- and returns the ranks' exit code.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        print("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)", file=sys.stderr)
+        return 2
+    if ndev < args.gpus and not args.share_device:
+        print(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible on this node (one rank per GPU; "
+              f"--share-device puts every rank on device 0 to exercise the multi-rank path on a smaller box)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus}: launching {args.gpus} ranks ({' '.join(cmd[1:9])} ...)")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +220,7 @@ def main():
     ap.add_argument("--no-concurrent", action="store_true", help="skip the two-caller-threads reference measurement")
     ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
     ap.add_argument("--dump-stats", default="", help="write the per-query kernel stats of the last step to this .npy")
+    ap.add_argument("--dump-answers", default="", help="write the answers of batch 0 (all ranks' shards gathered, input order) to this .npz")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (gloo only to exercise the multi-rank path on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (1-GPU box test of the N>1 path)")
@@ -203,6 +229,9 @@ def main():
                     "re-searches the batch of the previous step finds its rows in the 256 MiB Infinity Cache)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # the plain command: this process launches one rank per GPU and waits for them
+
     import torch  # first: the C-ABI library then binds to the HIP runtime torch already loaded
     import hnsw_rs_amd as H
 
@@ -210,25 +239,56 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): pass the same number to both")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
     if args.share_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: HIP device {local_rank} does not exist ({torch.cuda.device_count()} visible); one rank per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_pg = None
+    rccl = None
+    backend_used = args.backend
     if world > 1:
         import datetime
         import torch.distributed as dist_pg_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        fallback_reason = None
         if args.backend == "nccl":
-            dist_pg_mod.init_process_group("nccl", timeout=datetime.timedelta(hours=2), device_id=dev)
+            try:
+                # backend "nccl" IS RCCL on ROCm; the communicator is created here (device_id), so a refusal shows up now
+                dist_pg_mod.init_process_group("nccl", timeout=datetime.timedelta(minutes=30), device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist_pg_mod.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+            except Exception as e:  # noqa: BLE001
+                # RCCL refuses two ranks on ONE device ("Duplicate GPU detected"): only on a --share-device run of the
+                # multi-rank path is that a reason to gather over gloo instead -- and the line says which backend ran
+                if not args.share_device:
+                    raise
+                fallback_reason = f"{type(e).__name__}: {str(e).splitlines()[0][:200]}"
+                log(f"rank {rank}: RCCL refused the shared device ({fallback_reason}); gathering over gloo")
+                try:
+                    if dist_pg_mod.is_initialized():
+                        dist_pg_mod.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend_used = "gloo"
+                port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+                dist_pg_mod.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                               timeout=datetime.timedelta(hours=2))
         else:
             dist_pg_mod.init_process_group("gloo", timeout=datetime.timedelta(hours=2))
         dist_pg = dist_pg_mod
-    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo collectives run on host tensors
+    coll_dev = dev if backend_used == "nccl" else torch.device("cpu")  # gloo collectives run on host tensors
+    if world > 1:
+        seen = torch.ones(1, dtype=torch.int64, device=coll_dev)
+        dist_pg.all_reduce(seen)  # every rank of the group adds one: the ranks this communicator really spans
+        rccl = {"backend": dist_pg.get_backend(), "requested": args.backend, "ranks_seen": int(seen.item()),
+                "library": ("RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())) if backend_used == "nccl" else "gloo (host tensors)",
+                "fallback_reason": fallback_reason, "devices": "all ranks on HIP device 0 (--share-device)" if args.share_device else "one HIP device per rank"}
 
     cfg = dict(CONFIGS[args.config])
     if args.n:
@@ -294,6 +354,7 @@ def main():
     if world > 1:
         gathered_ids = torch.empty((nq_total, k), dtype=torch.int64, device=coll_dev)
         gathered_dists = torch.empty((nq_total, k), dtype=torch.float32, device=coll_dev)
+        gathered_counts = torch.empty((nq_total,), dtype=torch.int32, device=coll_dev)
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
@@ -311,6 +372,7 @@ def main():
         if world > 1:  # the only exchange on this path: gather of the answers (RCCL over xGMI)
             dist_pg.all_gather_into_tensor(gathered_ids, out_ids.to(coll_dev))
             dist_pg.all_gather_into_tensor(gathered_dists, out_dists.to(coll_dev))
+            dist_pg.all_gather_into_tensor(gathered_counts, out_counts.to(coll_dev))
 
     def fence():
         if world > 1:
@@ -400,6 +462,11 @@ def main():
             two_callers_qps = None
     step(0)   # leave the strict answers of batch 0 in the output buffers for the recall / parity checks below
     fence()
+    if args.dump_answers and rank == 0:  # batch 0 in input order: what the caller of parallel_search gets back
+        if world > 1:
+            np.savez(args.dump_answers, ids=gathered_ids.cpu().numpy(), dists=gathered_dists.cpu().numpy(), counts=gathered_counts.cpu().numpy())
+        else:
+            np.savez(args.dump_answers, ids=out_ids.cpu().numpy(), dists=out_dists.cpu().numpy(), counts=out_counts.cpu().numpy())
 
     # ---------------------------------------------------------------- recall vs exact brute force
     res_ids = out_ids.cpu().numpy()
@@ -468,6 +535,9 @@ def main():
                 "queries_resolved_with_literal_heaps": int((st[:, 3] == 3).sum()),
                 "queries_that_met_equal_distances": int((st[:, 7] & 1).sum()),
                 "launches_per_step": index.last_kernel_ms()[1], "query_batches_rotated": NB,
+                # the batches differ (their longest search sets a launch's length): spread of the timed launches per batch
+                "kernel_ms_by_batch_min_median_max": {str(b): [round(float(f(v)), 4) for f in (np.min, np.median, np.max)]
+                                                      for b in range(NB) for v in [[m for i, m in enumerate(timed_main_ms) if i % NB == b]] if v},
                 "index_bytes_in_hbm": int(index_bytes),
                 "resident_in_infinity_cache": bool(index_bytes < 256 * 2 ** 20),
                 "note": ("the whole index fits the 256 MiB Infinity Cache: the fetches behind `achieved` are served by MALL/L2, "
@@ -492,7 +562,10 @@ def main():
             "dtype": "f32", "data": f"synthetic ({args.data}, seeds 0x5EED0001/0x5EED0002), graph built by the product builder ({'host cores' if args.host_build else 'GPU-assisted construction'})",
             "config": {"workload": cfg["label"], "n": n, "d": d, "distance": cfg["dist"], "M": cfg["M"],
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
-                       "queries_total": nq_total, "graph": "replicated per GPU", "exchange": "all_gather of answers (RCCL)" if world > 1 else "none"},
+                       "queries_total": nq_total, "graph": "replicated per GPU",
+                       "exchange": ("all_gather of the answers (ids, distances, counts) over %s" % ("RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
+                       "parallelism": f"{world} x (replica + {nq_local} queries)"},
+            "rccl": rccl,
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
             "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},

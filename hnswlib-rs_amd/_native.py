@@ -7,14 +7,24 @@ import ctypes as C
 import os
 import subprocess
 
+from . import _cheader
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libhnsw_mi355x.so")
 # tuning hook: load a differently-built variant of the same library (kernel A/B runs in one process tree)
 LIB_OVERRIDE = os.environ.get("HNSW_MI355X_LIB")
 
-OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY, ERR_REF_PANIC = range(9)
-DIST = {"DistL2": 0, "DistCosine": 1, "DistDot": 2, "DistL1": 3, "DistHellinger": 4, "DistJeffreys": 5, "DistJensenShannon": 6}
+HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "hnsw_mi355x.h")
+# The header is the one description of the C ABI; structures, prototypes and codes below are READ FROM IT (._cheader).
+HEADER = _cheader.load(HEADER_PATH)
+OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY, ERR_REF_PANIC = (
+    HEADER.constants["HNSWGPU_" + n] for n in ("OK", "ERR_ARG", "ERR_IO", "ERR_FORMAT", "ERR_DISTANCE", "ERR_TYPE", "ERR_DEVICE",
+                                               "ERR_EMPTY", "ERR_REF_PANIC"))
+DIST = {"DistL2": HEADER.constants["HNSWGPU_DIST_L2"], "DistCosine": HEADER.constants["HNSWGPU_DIST_COSINE"],
+        "DistDot": HEADER.constants["HNSWGPU_DIST_DOT"], "DistL1": HEADER.constants["HNSWGPU_DIST_L1"],
+        "DistHellinger": HEADER.constants["HNSWGPU_DIST_HELLINGER"], "DistJeffreys": HEADER.constants["HNSWGPU_DIST_JEFFREYS"],
+        "DistJensenShannon": HEADER.constants["HNSWGPU_DIST_JENSENSHANNON"]}
 DIST_NAME = {v: k for k, v in DIST.items()}
 
 
@@ -22,7 +32,7 @@ def build_native(force=False, verbose=False):
     """Compile every HIP/C++ source for gfx950 into libhnsw_mi355x.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)
             if f.endswith((".cpp", ".hip", ".hpp", ".inc")) or f == "Makefile"]
-    srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "hnsw_mi355x.h"))
+    srcs.append(HEADER_PATH)
 
     def fresh():
         return (os.path.exists(LIB_PATH)
@@ -48,107 +58,16 @@ def build_native(force=False, verbose=False):
     return LIB_PATH
 
 
-class Description(C.Structure):
-    _fields_ = [("format_version", C.c_uint32), ("dumpmode", C.c_uint8), ("max_nb_connection", C.c_uint8),
-                ("nb_layer", C.c_uint8), ("level_scale", C.c_double), ("ef_construction", C.c_uint64),
-                ("nb_point", C.c_uint64), ("dimension", C.c_uint64), ("distname", C.c_char * 260),
-                ("t_name", C.c_char * 260)]
+# the header's structures (ctypes.Structure classes generated from its typedefs)
+Description = HEADER.structs["hnswgpu_description"]
+BuildParams = HEADER.structs["hnswgpu_build_params"]
+Neighbour_api = HEADER.structs["Neighbour_api"]                    # src/libext.rs:64-71
+Neighbourhood_api = HEADER.structs["Neighbourhood_api"]            # src/libext.rs:82-87
+Vec_api_Neighbourhood = HEADER.structs["Vec_api_Neighbourhood"]    # src/libext.rs:58-62
+DescriptionFFI = HEADER.structs["DescriptionFFI"]                  # src/libext.rs:1121-1141
 
-
-class BuildParams(C.Structure):
-    _fields_ = [("max_nb_connection", C.c_uint64), ("ef_construction", C.c_uint64), ("max_layer", C.c_uint64),
-                ("dist", C.c_int), ("level_scale_factor", C.c_double), ("extend_candidates", C.c_int),
-                ("keep_pruned", C.c_int), ("nthreads", C.c_int), ("fast_arithmetic", C.c_int), ("gpu_assist", C.c_int),
-                ("gpu_device", C.c_int), ("gpu_window", C.c_uint64)]
-
-
-class Neighbour_api(C.Structure):  # src/libext.rs:64-71
-    _fields_ = [("id", C.c_size_t), ("d", C.c_float)]
-
-
-class Neighbourhood_api(C.Structure):  # src/libext.rs:82-87
-    _fields_ = [("nbgh", C.c_int64), ("neighbours", C.POINTER(Neighbour_api))]
-
-
-class Vec_api_Neighbourhood(C.Structure):  # src/libext.rs:58-62
-    _fields_ = [("len", C.c_int64), ("ptr", C.POINTER(Neighbourhood_api))]
-
-
-class DescriptionFFI(C.Structure):  # src/libext.rs:1121-1141
-    _fields_ = [("dumpmode", C.c_uint8), ("max_nb_connection", C.c_uint8), ("nb_layer", C.c_uint8),
-                ("ef", C.c_size_t), ("nb_point", C.c_size_t), ("data_dimension", C.c_size_t),
-                ("distname_len", C.c_size_t), ("distname", C.c_void_p), ("t_name_len", C.c_size_t),
-                ("t_name", C.c_void_p)]
-
-
-# every symbol include/hnsw_mi355x.h declares: (restype, argtypes)
-_VP, _U64, _SZ, _I = C.c_void_p, C.c_uint64, C.c_size_t, C.c_int
-SYMBOLS = {
-    "hnswgpu_last_error": (C.c_char_p, []),
-    "hnswgpu_load_dump": (_I, [C.c_char_p, C.c_char_p, _I, C.POINTER(_VP)]),
-    "hnswgpu_file_dump": (_I, [_VP, C.c_char_p, C.c_char_p]),
-    "hnswgpu_free_index": (None, [_VP]),
-    "hnswgpu_load_description": (_I, [C.c_char_p, C.POINTER(Description)]),
-    "hnswgpu_get_description": (_I, [_VP, C.POINTER(Description)]),
-    "hnswgpu_datamap_open": (_I, [C.c_char_p, C.c_char_p, C.POINTER(_VP)]),
-    "hnswgpu_datamap_close": (None, [_VP]),
-    "hnswgpu_datamap_get_data": (_VP, [_VP, _U64]),
-    "hnswgpu_datamap_nb_data": (_U64, [_VP]),
-    "hnswgpu_datamap_dimension": (_U64, [_VP]),
-    "hnswgpu_datamap_distname": (C.c_char_p, [_VP]),
-    "hnswgpu_datamap_typename": (C.c_char_p, [_VP]),
-    "hnswgpu_datamap_ids": (_U64, [_VP, _VP, _U64]),
-    "hnswgpu_build": (_I, [_VP, _U64, _U64, _VP, C.POINTER(BuildParams), C.POINTER(_VP)]),
-    "hnswgpu_insert": (_I, [_VP, _VP, _U64, _U64, _VP, _I]),
-    "hnswgpu_insert_gpu": (_I, [_VP, _VP, _U64, _U64, _VP, _I, _I, _U64]),
-    "hnswgpu_nb_point": (_U64, [_VP]),
-    "hnswgpu_dimension": (_U64, [_VP]),
-    "hnswgpu_dist": (_I, [_VP]),
-    "hnswgpu_layer_nb_point": (_U64, [_VP, C.c_uint]),
-    "hnswgpu_max_level_observed": (_I, [_VP]),
-    "hnswgpu_entry_point": (_I, [_VP, _VP, _VP, _VP]),
-    "hnswgpu_neighbours": (C.c_int64, [_VP, C.c_uint, C.c_int32, C.c_uint, _U64, _VP, _VP, _VP, _VP]),
-    "hnswgpu_upload": (_I, [_VP, _I]),
-    "hnswgpu_device_count": (_I, []),
-    "hnswgpu_search_batch": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
-    "hnswgpu_search_batch_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "hnswgpu_search_batch_device_begin": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "hnswgpu_search_batch_end": (_I, [_VP]),
-    "hnswgpu_search_batch_filtered": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "hnswgpu_search_batch_sharded": (_I, [_VP, _VP, _I, _VP, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP, _VP]),
-    "hnswgpu_search_batch_filtered_device": (_I, [_VP, _VP, _U64, _U64, _U64, _U64, _VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP,
-                                                  _VP, C.POINTER(C.c_uint32)]),
-    "hnswgpu_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
-    "hnswgpu_last_search_kernel_ms": (_I, [_VP, C.POINTER(C.c_double)]),
-    "hnswgpu_set_strict_ties": (_I, [_VP, _I]),
-    "hnswgpu_last_tie_count": (_I, [_VP, C.POINTER(C.c_uint32)]),
-    "hnswgpu_eval_distances": (_I, [_I, _VP, _VP, _U64, _U64, _VP]),
-    "hnswgpu_eval_distance_matrix": (_I, [_I, _VP, _U64, _VP, _U64, _U64, C.c_uint32, _VP]),
-    # reference-compatible symbols (src/libext.rs)
-    "get_hnswio": (_VP, [_U64, C.c_char_p]),
-    "load_hnswdump_f32_DistL1": (_VP, [_VP]),
-    "load_hnswdump_f32_DistL2": (_VP, [_VP]),
-    "load_hnswdump_f32_DistCosine": (_VP, [_VP]),
-    "load_hnswdump_f32_DistDot": (_VP, [_VP]),
-    "load_hnswdump_f32_DistJensenShannon": (_VP, [_VP]),
-    "load_hnswdump_f32_DistJeffreys": (_VP, [_VP]),
-    "init_hnsw_f32": (_VP, [_SZ, _SZ, _SZ, C.c_char_p]),
-    "new_hnsw_f32": (_VP, [_SZ, _SZ, _SZ, C.c_char_p, _SZ, _SZ]),
-    "init_hnsw_ptrdist_f32": (_VP, [_SZ, _SZ, _VP]),
-    "insert_f32": (None, [_VP, _SZ, _VP, _SZ]),
-    "parallel_insert_f32": (None, [_VP, _SZ, _SZ, _VP, _VP]),
-    "search_neighbours_f32": (C.POINTER(Neighbourhood_api), [_VP, _SZ, _VP, _SZ, _SZ]),
-    "parallel_search_neighbours_f32": (C.POINTER(Vec_api_Neighbourhood), [_VP, _SZ, C.c_int64, _VP, _SZ, _SZ]),
-    "file_dump_f32": (C.c_int64, [_VP, _SZ, C.c_char_p]),
-    "drop_hnsw_f32": (None, [_VP]),
-    "load_hnsw_description": (C.POINTER(DescriptionFFI), [_SZ, C.c_char_p]),
-    "init_rust_log": (None, []),
-    "hnswgpu_free_neighbourhood": (None, [C.POINTER(Neighbourhood_api)]),
-    "hnswgpu_free_neighbourhood_vec": (None, [C.POINTER(Vec_api_Neighbourhood)]),
-    "hnswgpu_free_hnswio": (None, [_VP]),
-    "hnswgpu_free_description": (None, [C.POINTER(DescriptionFFI)]),
-    "hnswgpu_from_api": (_VP, [_VP]),
-}
+# every symbol include/hnsw_mi355x.h declares: name -> (restype, argtypes)
+SYMBOLS = {name: (res, args) for name, (res, args, _names, _text) in HEADER.prototypes.items()}
 
 _lib = None
 

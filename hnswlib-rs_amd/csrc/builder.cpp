@@ -612,8 +612,12 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
                                    BuildSearchBackend& dev, uint64_t max_window, std::string& err) {
     if (n == 0) return OK;
     if (n_ + n >= (1ull << 28)) { err = "GPU-assisted construction: too many points (dirty-list ids are 28 bits)"; return ERR_ARG; }
+    warning_.clear();
+    // what can be refused up front is refused before a single point is accepted: the index is then unchanged
+    int rc = dev.check(p_.ef_construction, err);
+    if (rc != OK) return rc;
     const uint64_t first = n_;
-    int rc = append_points(data, n, d, ids, err);
+    rc = append_points(data, n, d, ids, err);
     if (rc != OK) return rc;
     // host side of a window: 32 threads unless told otherwise -- measured on a 256-thread host, 1M x 128: 32 threads
     // 5.5 s for the whole build, 64 threads 6.3 s, 256 threads 10.9 s (the spin locks of popular nodes and the per-window
@@ -627,6 +631,28 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
     const uint64_t boot_until = max_window == 1 ? std::min<uint64_t>(n_, std::max<uint64_t>(first, 1)) : std::min<uint64_t>(n_, std::max<uint64_t>(first, 1024));
     for (; start < boot_until; ++start) insert_one((uint32_t)start, t0);
     if (start >= n_) return OK;
+    // A device failure from here on (allocation, copy, kernel) finds the batch half inserted.  The points were accepted,
+    // so they are linked: the host builder finishes [start, n_) (every window before `start` is complete), the call
+    // succeeds, and the device's message is kept as a warning (last_warning()).
+    auto finish_on_host = [&](const std::string& why) -> int {
+        warning_ = "GPU-assisted construction fell back to the host builder for " + std::to_string(n_ - start) + " points: " + why;
+        err.clear();
+        std::atomic<uint64_t> next{start};
+        auto worker = [&]() {
+            Tls t;
+            for (;;) {
+                const uint64_t i = next.fetch_add(1);
+                if (i >= n_) break;
+                insert_one((uint32_t)i, t);
+            }
+        };
+        std::vector<std::thread> th;
+        const int nt = n_ - start < 64 ? 1 : nthreads;
+        for (int k = 1; k < nt; ++k) th.emplace_back(worker);
+        worker();
+        for (auto& x : th) x.join();
+        return OK;
+    };
     // the device gets every vector and level, and the lists as they are now
     unsigned top_layer = 0;
     std::vector<uint8_t> levels(n_);
@@ -635,7 +661,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
     for (auto& c : vecs_) chunk_ptrs.push_back(c.get());
     rc = dev.begin(chunk_ptrs.data(), CHUNK, n_, d_, levels.data(), p_.dist, p_.max_nb_connection, p_.ef_construction, top_layer,
                    max_window, err);
-    if (rc != OK) return rc;
+    if (rc != OK) return finish_on_host(err);
     const uint32_t rw = dev.rec_words();
     std::vector<uint32_t> records;
     auto pack = [&](const std::vector<uint32_t>& dirty) {
@@ -663,7 +689,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
             }
         pack(dirty);
         rc = dev.patch(records, err);
-        if (rc != OK) return rc;
+        if (rc != OK) return finish_on_host(err);
     }
     WindowSearchResults res;
     std::vector<std::vector<uint32_t>> dirty_t((size_t)nthreads);
@@ -682,7 +708,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
             if (layer_inserted_[l].load(std::memory_order_acquire) > 0) layer_mask |= 1u << l;
         const double w0 = now();
         rc = dev.search_window((uint32_t)start, count, frozen_entry, frozen_level, layer_mask, res, err);
-        if (rc != OK) return rc;
+        if (rc != OK) return finish_on_host(err);
         const double w1 = now();
         for (auto& v : dirty_t) v.clear();
         std::atomic<uint32_t> next{0};
@@ -735,9 +761,9 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
             pack_slice(0);
             for (auto& x : th2) x.join();
         }
+        start += count;  // this window is linked on the host whatever happens to the snapshot
         rc = dev.patch(records, err);
-        if (rc != OK) return rc;
-        start += count;
+        if (rc != OK) { if (start < n_) return finish_on_host(err); warning_ = err; err.clear(); return OK; }
         t_search += w1 - w0;
         t_apply += w2 - w1;
         t_patch += now() - w2;

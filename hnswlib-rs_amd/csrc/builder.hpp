@@ -49,6 +49,9 @@ struct WindowSearchResults {
 class BuildSearchBackend {
 public:
     virtual ~BuildSearchBackend() = default;
+    // can this backend serve a build with these parameters at all (a device is visible, the ordinal exists, ef_construction is
+    // supported)?  Called BEFORE any point is accepted, so that these failures leave the index unchanged.
+    virtual int check(uint64_t ef_construction, std::string& err) = 0;
     // all vectors of the build (builder order, n x d) and every point's level; empty lists everywhere
     virtual int begin(const float* const* chunks, uint64_t chunk_rows, uint64_t n, uint64_t d, const uint8_t* levels, int dist,
                       uint64_t max_nb_connection, uint64_t ef_construction, unsigned top_layer, uint64_t max_window,
@@ -80,6 +83,8 @@ public:
     uint64_t nb_point() const { return n_; }
     uint64_t dimension() const { return d_; }
     const BuildParams& params() const { return p_; }
+    // set by insert_batch_gpu when a device failure made the host builder finish the batch (the call still succeeded)
+    const std::string& last_warning() const { return warning_; }
     // flatten into dump order
     void finalize(FlatIndex& out) const;
 
@@ -114,6 +119,7 @@ private:
     std::mutex entry_mutex_;
     std::atomic<int64_t> entry_{-1};
     std::atomic<int> entry_level_{-1};
+    std::string warning_;  // insert_batch_gpu: why the host builder finished the batch (empty: it did not)
 };
 
 // convenience: Hnsw::new + parallel_insert of a whole data set, flattened

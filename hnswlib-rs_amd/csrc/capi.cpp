@@ -25,6 +25,8 @@ static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+// a call that SUCCEEDED with something worth telling (hnswgpu_last_error() returns it until the next failure or note)
+static void note(const std::string& msg) { g_last_error = msg; }
 // No C++ exception may cross the C ABI (the host may be Rust, Julia or C): every entry point runs inside this guard.
 #define CAPI_GUARD_BEGIN try {
 #define CAPI_GUARD_END(ret)                                                             \
@@ -218,6 +220,7 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
     if (h->params.gpu_device >= 0) {
         std::unique_ptr<BuildSearchBackend> dev = make_device_build_backend(h->params.gpu_device);
         rc = h->builder->insert_batch_gpu(data, n, d, ids, h->params.nthreads, *dev, h->params.gpu_window, err);
+        if (rc == OK && !h->builder->last_warning().empty()) note(h->builder->last_warning());
     } else {
         rc = h->builder->insert_batch(data, n, d, ids, h->params.nthreads, err);
     }
@@ -242,6 +245,7 @@ static int insert_points(hnswgpu_index* idx, const float* data, uint64_t n, uint
     if (gpu_device >= 0) {
         std::unique_ptr<BuildSearchBackend> dev = make_device_build_backend(gpu_device);
         rc = idx->builder->insert_batch_gpu(data, n, d, ids, nthreads, *dev, gpu_window, err);
+        if (rc == OK && !idx->builder->last_warning().empty()) note(idx->builder->last_warning());
     } else {
         rc = idx->builder->insert_batch(data, n, d, ids, nthreads, err);
     }
@@ -721,7 +725,8 @@ const HnswApif32* init_hnsw_ptrdist_f32(size_t, size_t, hnsw_dist_fn_f32) {
 }
 
 // The reference's insert_f32 / parallel_insert_f32 return nothing (:661-723).  They work on every handle, reloaded ones
-// included; a failure (dimension mismatch, ...) leaves the index unchanged and is readable through hnswgpu_last_error().
+// included; a failure (dimension mismatch, no device, bad ordinal, ...) leaves the index unchanged and is readable through
+// hnswgpu_last_error().
 void insert_f32(HnswApif32* api, size_t len, const float* data, size_t id) {
     CAPI_GUARD_BEGIN
     if (!api || !api->idx || !data) { fail(HNSWGPU_ERR_ARG, "insert_f32: null argument"); return; }

@@ -74,6 +74,27 @@ hipError_t wait_event(hipEvent_t ev) {
     }
 }
 
+// Every entry point works on the replica's device and leaves the CALLER's current HIP device as it found it (a host
+// thread shared with PyTorch, a Rust or a Julia runtime keeps allocating and launching where it did before the call).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur == device) return;
+        status_ = hipSetDevice(device);
+        if (status_ == hipSuccess && cur >= 0) prev_ = cur;
+    }
+    ~DeviceGuard() { if (prev_ >= 0) (void)hipSetDevice(prev_); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    hipError_t status() const { return status_; }
+private:
+    int prev_ = -1;
+    hipError_t status_ = hipSuccess;
+};
+
 uint32_t ceil_log2(uint64_t x) {
     uint32_t b = 0;
     while ((1ull << b) < x) ++b;
@@ -188,7 +209,7 @@ DeviceIndex::DeviceIndex() = default;
 DeviceIndex::~DeviceIndex() { release(); }
 
 void DeviceIndex::release() {
-    if (device_ >= 0) (void)hipSetDevice(device_);
+    DeviceGuard on_device(device_);
     {
         std::lock_guard<std::mutex> g(pool_mu_);
         free_ws_.clear();
@@ -214,7 +235,8 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device visible (a gfx950 GPU is required; there is no CPU fallback)"; return ERR_DEVICE; }
     if (device < 0 || device >= ndev) { err = "bad device ordinal"; return ERR_ARG; }
     release();
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard on_device(device);
+    HIP_TRY(on_device.status());
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     num_cu_ = prop.multiProcessorCount;
@@ -383,7 +405,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     if (nq > 0xFFFFFFF0ull) { err = "too many queries in one batch"; return ERR_ARG; }
     const bool filtered = d_allowed != nullptr || n_allowed != 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    HIP_TRY(hipSetDevice(device_));
+    DeviceGuard on_device(device_);
+    HIP_TRY(on_device.status());
     Lease lease(this, acquire(err));
     if (!lease.get()) return ERR_DEVICE;
     Workspace& w = *lease.get();
@@ -614,7 +637,8 @@ int DeviceIndex::search_host(const float* queries, uint64_t nq, uint64_t d, uint
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
     if (k == 0) { err = "knbn must be > 0"; return ERR_ARG; }
     if (filtered && n_allowed && !allowed) { err = "null filter"; return ERR_ARG; }
-    HIP_TRY(hipSetDevice(device_));
+    DeviceGuard on_device(device_);
+    HIP_TRY(on_device.status());
     // the staging buffers live in their own workspace: search_device takes a second one for its scratch
     Lease lease(this, acquire(err));
     if (!lease.get()) return ERR_DEVICE;
@@ -669,18 +693,24 @@ class DeviceBuildBackend : public BuildSearchBackend {
 public:
     explicit DeviceBuildBackend(int device) : device_(device) {}
     ~DeviceBuildBackend() override {
-        if (device_ >= 0) (void)hipSetDevice(device_);
+        DeviceGuard on_device(device_);
         for (DevBuf* b : {&vec_, &level_, &nrm2_, &slot0_, &out_ids_, &out_d_, &out_n_, &hit_ids_, &hit_d_, &bitmap_, &upd_}) b->free();
         for (auto& b : lists_) b.free();
         if (d_ctrl_) (void)hipFree(d_ctrl_);
     }
-    int begin(const float* const* chunks, uint64_t chunk_rows, uint64_t n, uint64_t d, const uint8_t* levels, int dist,
-              uint64_t max_nb_connection, uint64_t ef_construction, unsigned top_layer, uint64_t max_window, std::string& err) override {
+    int check(uint64_t ef_construction, std::string& err) override {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device visible (GPU-assisted construction needs a gfx950 GPU)"; return ERR_DEVICE; }
         if (device_ < 0 || device_ >= ndev) { err = "bad device ordinal"; return ERR_ARG; }
         if (ef_construction > 1024) { err = "GPU-assisted construction supports ef_construction up to 1024"; return ERR_ARG; }
-        HIP_TRY(hipSetDevice(device_));
+        return OK;
+    }
+    int begin(const float* const* chunks, uint64_t chunk_rows, uint64_t n, uint64_t d, const uint8_t* levels, int dist,
+              uint64_t max_nb_connection, uint64_t ef_construction, unsigned top_layer, uint64_t max_window, std::string& err) override {
+        const int crc = check(ef_construction, err);
+        if (crc != OK) return crc;
+        DeviceGuard on_device(device_);
+        HIP_TRY(on_device.status());
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_));
         num_cu_ = prop.multiProcessorCount;
@@ -722,7 +752,8 @@ public:
     uint32_t rec_words() const override { return 2u + max_stride_; }
     int patch(const std::vector<uint32_t>& records, std::string& err) override {
         if (records.empty()) return OK;
-        HIP_TRY(hipSetDevice(device_));
+        DeviceGuard on_device(device_);
+        HIP_TRY(on_device.status());
         const uint32_t rw = rec_words();
         const uint32_t n_upd = (uint32_t)(records.size() / rw);
         for (uint32_t u = 0; u < n_upd; ++u)
@@ -735,7 +766,8 @@ public:
     }
     int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask, WindowSearchResults& out,
                       std::string& err) override {
-        HIP_TRY(hipSetDevice(device_));
+        DeviceGuard on_device(device_);
+        HIP_TRY(on_device.status());
         if (entry_level > top_layer_) { err = "internal error: entry point above the snapshot's layers"; return ERR_ARG; }
         // output slots: one per (point, layer <= min(level, entry level))
         levels_h_.resize(count);

@@ -138,7 +138,11 @@ int hnswgpu_build(const float* data, uint64_t n, uint64_t d, const uint64_t* ids
  * kept).  nthreads: 1 = serial, 0 = all host cores.  HBM replicas are refreshed by the next search / upload.           */
 int hnswgpu_insert(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids /* NULL: continue */,
                    int nthreads);
-/* the same, GPU-assisted (see hnswgpu_build_params.gpu_assist / gpu_device / gpu_window)                                 */
+/* the same, GPU-assisted (see hnswgpu_build_params.gpu_assist / gpu_device / gpu_window).  What can be refused up front (no
+ * device, bad ordinal, ef_construction > 1024, wrong dimension) is refused before a point is accepted: the index is then
+ * unchanged and a retry is safe.  A device failure AFTER the points were accepted (allocation, copy, kernel) does not lose
+ * them: the host builder links the rest of the batch, the call returns HNSWGPU_OK and hnswgpu_last_error() holds the device's
+ * message as a warning.  Either way hnswgpu_nb_point() counts fully linked points only.                                    */
 int hnswgpu_insert_gpu(hnswgpu_index* idx, const float* data, uint64_t n, uint64_t d, const uint64_t* ids, int nthreads,
                        int gpu_device, uint64_t gpu_window);
 

@@ -163,3 +163,35 @@ def test_reloaded_index_keeps_growing_like_the_oracle(native, oracle, tmp_path, 
     finally:
         os.chdir(cwd)
     assert dumps_equal(tmp_path, "orc_full", "ffi_full")
+
+
+def test_gpu_insert_without_a_device_leaves_the_index_unchanged(native, tmp_path):
+    """hnswgpu_insert_gpu / GPU-assisted hnswgpu_build on a box without a usable device: refused BEFORE a point is accepted
+    (BuildSearchBackend::check), so nb_point, the dump and a plain retry on the host are what they would have been."""
+    import torch
+    if torch.cuda.is_available():
+        bad_device = torch.cuda.device_count() + 3   # a GPU box: an ordinal that does not exist
+    else:
+        bad_device = 0
+    n, d, m = 2000, 12, 8
+    X, Y = uniform(n, d, 31), uniform(500, d, 32)
+    h = native.Hnsw(m, n + 1000, 16, 60, "DistL2")
+    h.insert_serial(X)
+    h.file_dump(tmp_path, "before")
+    h.set_build_options(gpu_device=bad_device, gpu_window=0)
+    for _ in range(2):  # a retry must not pile up half-inserted points either
+        with pytest.raises(native.HnswError):
+            h.parallel_insert(Y)
+        assert h.get_nb_point() == n
+    h.file_dump(tmp_path, "after")
+    assert dumps_equal(tmp_path, "before", "after")
+    # the same batch through the host builder: the index grows by exactly the batch
+    h.set_build_options(gpu_device=-1, nthreads=1)
+    h.parallel_insert(Y)
+    assert h.get_nb_point() == n + 500
+    assert sum(h.get_layer_nb_point(l) for l in range(16)) == n + 500
+    # ... and a GPU-assisted build from scratch without a device fails without producing a handle
+    g = native.Hnsw(m, n, 16, 60, "DistL2")
+    g.set_build_options(gpu_device=bad_device, gpu_window=0)
+    with pytest.raises(native.HnswError):
+        g.parallel_insert(X)

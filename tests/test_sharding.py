@@ -63,3 +63,15 @@ def test_two_rank_gloo_search_equals_unsharded(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 2
+
+
+def test_bench_gpus_n_is_a_plain_command():
+    """`python bench.py --gpus N` (N > 1) launches its own ranks; with fewer HIP devices than N it ends at once with a
+    clear message and a non-zero code -- never a hang, never a launcher requirement."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("a box with 64 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, r.stdout + r.stderr
+    assert "HIP device" in r.stderr and not r.stdout.strip()
