@@ -36,6 +36,9 @@ CONFIGS = {
                    label="SIFT1M-shape synthetic 1Mx128 f32 L2 M=16 ef=64"),
     "glove25": dict(n=1_200_000, d=25, dist="DistCosine", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000,
                     label="GloVe-25-shape synthetic 1.2Mx25 f32 cosine M=24 ef=128"),
+    # the reference's own choice for this data set: DistDot on L2-normalised vectors (examples/ann-glove25-angular.rs:81-82, :107-108)
+    "glove25_dot": dict(n=1_200_000, d=25, dist="DistDot", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000,
+                        label="GloVe-25-shape synthetic 1.2Mx25 f32, L2-normalised, DistDot M=24 ef=128"),
     "mnist784": dict(n=60_000, d=784, dist="DistL2", M=32, efc=400, k=10, ef=200, nq=10_000, nq_multi=10_000,
                      label="MNIST-784-shape synthetic 60kx784 f32 L2 M=32 ef=200"),
     "random10k": dict(n=10_000, d=25, dist="DistL2", M=15, efc=200, k=10, ef=24, nq=1_000, nq_multi=1_000,
@@ -196,10 +199,72 @@ def spawn_ranks(args):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    # this command's own arguments travel in the environment: the launcher's option parser would try to claim the ones that
+    # look like prefixes of its own options (--n ...)
+    env["HNSW_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)]
     log(f"--gpus {args.gpus}: launching {args.gpus} ranks ({' '.join(cmd[1:9])} ...)")
     return subprocess.call(cmd, env=env)
+
+
+def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=5):
+    """What a caller pays above the device-buffer call (reported next to `value`, never as `value`):
+    * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (H2D + kernels + D2H);
+    * ffi: the reference's own symbol parallel_search_neighbours_f32 (src/libext.rs:205-254) on a handle loaded the
+      reference's way (get_hnswio + load_hnswdump_f32_<Dist>): array of row pointers in, Vec_api<Neighbourhood_api> out,
+      freed with hnswgpu_free_neighbourhood_vec;
+    * filtered: Hnsw::search_filter with a sorted id vector allowing 1 % / 30 % of the points (literal-heap kernel)."""
+    nq, d = Q.shape
+    out = {}
+
+    def rate(fn, nrep=reps):
+        fn()
+        ts = []
+        for _ in range(nrep):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return nq / float(np.median(ts))
+
+    out["host_buffers_queries_per_s"] = round(rate(lambda: index.parallel_search_flat(Q, k, ef)), 1)
+    loader = getattr(lib, "load_hnswdump_f32_" + dist_name, None)
+    if loader is not None:
+        cwd = os.getcwd()
+        os.chdir(cache_dir)  # get_hnswio names a dump in the current directory (src/libext.rs:28-33)
+        try:
+            api = loader(lib.get_hnswio(len(base), base.encode()))
+        finally:
+            os.chdir(cwd)
+        if api:
+            rows = (C.c_void_p * nq)(*[Q.ctypes.data + i * d * 4 for i in range(nq)])
+            first = {}
+
+            def ffi_call():
+                v = lib.parallel_search_neighbours_f32(api, nq, d, rows, k, ef)
+                if not v:
+                    raise RuntimeError("parallel_search_neighbours_f32 returned NULL: " + H._native.last_error())
+                if not first:
+                    first["ids0"] = [v.contents.ptr[0].neighbours[j].id for j in range(v.contents.ptr[0].nbgh)]
+                lib.hnswgpu_free_neighbourhood_vec(v)
+
+            out["ffi_parallel_search_neighbours_f32_queries_per_s"] = round(rate(ffi_call), 1)
+            out["ffi_first_answer_ids"] = first.get("ids0")
+            lib.drop_hnsw_f32(api)
+    rng = np.random.default_rng(0xF117)
+    for pct in (1, 30):
+        allowed = np.sort(rng.choice(n, max(1, n * pct // 100), replace=False)).astype(np.uint64)  # origin ids = 0..n-1 here
+        sub = Q[: min(nq, 2000)]
+        t = []
+        index.parallel_search_filter_flat(sub, k, ef, allowed)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            index.parallel_search_filter_flat(sub, k, ef, allowed)
+            t.append(time.perf_counter() - t0)
+        out[f"filtered_{pct}pct_queries_per_s"] = round(sub.shape[0] / float(np.median(t)), 1)
+        out[f"filtered_{pct}pct_kernel_ms"] = round(index.last_kernel_ms()[0], 3)
+    out["filtered_note"] = "2 000 queries per call, host buffers, hnsw_search_exact_kernel (both heaps literal, allow bitmap built per call)"
+    return out
 
 
 def main():
@@ -219,6 +284,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the two-caller-threads reference measurement")
     ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the timings of the host-buffer / reference-FFI / filtered entry points")
     ap.add_argument("--dump-stats", default="", help="write the per-query kernel stats of the last step to this .npy")
     ap.add_argument("--dump-answers", default="", help="write the answers of batch 0 (all ranks' shards gathered, input order) to this .npz")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -227,7 +293,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the steps rotate through (a step that "
                     "re-searches the batch of the previous step finds its rows in the 256 MiB Infinity Cache)")
-    args = ap.parse_args()
+    args = ap.parse_args(json.loads(os.environ["HNSW_BENCH_ARGV"]) if "HNSW_BENCH_ARGV" in os.environ and len(sys.argv) == 1 else None)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # the plain command: this process launches one rank per GPU and waits for them
@@ -460,6 +526,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"two-caller measurement skipped: {e}")
             two_callers_qps = None
+    boundary = None
+    if world == 1 and not args.no_boundary:
+        try:  # informational figures: never at the expense of the line itself
+            boundary = boundary_timings(H, lib, index, args.cache_dir, base, cfg["dist"], Q, k, ef, n)
+        except Exception as e:  # noqa: BLE001
+            log(f"boundary timings skipped: {e}")
     step(0)   # leave the strict answers of batch 0 in the output buffers for the recall / parity checks below
     fence()
     if args.dump_answers and rank == 0:  # batch 0 in input order: what the caller of parallel_search gets back
@@ -570,6 +642,7 @@ def main():
             "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},
             "two_caller_threads_queries_per_s": None if two_callers_qps is None else round(two_callers_qps, 1),
+            "boundary": boundary,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_vs_oracle": parity,

@@ -330,12 +330,15 @@ class DataMap:
             N.lib().hnswgpu_datamap_close(h)
 
     def get_data(self, dataid):
-        """Option<&[f32]>: a read-only view into the mapping (valid while this object lives), or None."""
+        """Option<&[f32]>: a read-only view into the mapping, or None.  The view keeps this DataMap (and with it the mapping)
+        alive: it may outlive every other reference to the object."""
         p = N.lib().hnswgpu_datamap_get_data(self._h, int(dataid))
         if not p:
             return None
         d = self.get_dimension()
-        a = np.ctypeslib.as_array((C.c_float * d).from_address(p))
+        buf = (C.c_float * d).from_address(p)
+        buf._datamap = self  # the ctypes object is the array's base: the mapping cannot be unmapped under the view
+        a = np.ctypeslib.as_array(buf)
         a.flags.writeable = False
         return a
 

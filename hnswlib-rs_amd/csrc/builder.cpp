@@ -128,11 +128,21 @@ __attribute__((target_clones("avx2", "default"))) float cosine_fast(const float*
     return 0.f;
 }
 
+// a polite spin: the architecture's pause / yield hint where there is one
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
 struct SpinGuard {
     std::atomic<uint8_t>& l;
     explicit SpinGuard(std::atomic<uint8_t>& x) : l(x) {
         while (l.exchange(1, std::memory_order_acquire)) {
-            while (l.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+            while (l.load(std::memory_order_relaxed)) cpu_relax();
         }
     }
     ~SpinGuard() { l.store(0, std::memory_order_release); }
@@ -220,7 +230,10 @@ GraphBuilder::GraphBuilder(const FlatIndex& f, bool fast_arithmetic) {
     p_.extend_candidates = true;  // what load_hnsw sets on a reloaded index (src/hnswio.rs:510-511)
     p_.keep_pruned = false;
     p_.fast_arithmetic = fast_arithmetic;
-    max_layer_ = (unsigned)std::min<uint64_t>(NB_LAYER_MAX, std::max<uint64_t>(1, f.nb_layer));
+    // a reloaded reference index rebuilds its LayerGenerator with maxlevel = NB_LAYER_MAX whatever the dumped nb_layer was
+    // (src/hnswio.rs:773-777); the description that gets dumped again keeps the loaded nb_layer (dumped_nb_layer_)
+    max_layer_ = NB_LAYER_MAX;
+    dumped_nb_layer_ = (unsigned)std::min<uint64_t>(NB_LAYER_MAX, std::max<uint64_t>(1, f.nb_layer));
     // (the loader already applied the reference's reload rule to the dumped scale: see load_dump)
     scale_ = f.level_scale;
     p_.level_scale_factor = scale_ * std::log((double)std::max<uint64_t>(2, f.max_nb_connection));
@@ -247,6 +260,10 @@ GraphBuilder::GraphBuilder(const FlatIndex& f, bool fast_arithmetic) {
             const uint64_t b = f.nbr_ptr[i * NB_LAYER_MAX + l], e = f.nbr_ptr[i * NB_LAYER_MAX + l + 1];
             if (e == b) continue;
             std::vector<Edge>& lst = nd.list(l);
+            // reserved here, before any worker thread exists, to the most the list can reach (a longer list of a foreign dump
+            // included): readers copy lists without a lock and must never meet a reallocation
+            const size_t cap = (l == 0 ? 2 * (size_t)p_.max_nb_connection : (size_t)p_.max_nb_connection) + 2;
+            lst.reserve(std::max<size_t>(cap, (size_t)(e - b) + 2));
             lst.resize(e - b);
             for (uint64_t j = b; j < e; ++j) lst[j - b] = Edge{f.nbr_flat[j], f.nbr_dist[j]};
         }
@@ -301,7 +318,7 @@ void GraphBuilder::read_list(uint32_t id, unsigned layer, std::vector<Edge>& out
     static_assert(sizeof(Edge) == 8, "an edge is copied as one 64-bit word");
     for (;;) {
         const uint32_t s1 = nd.seq.load(std::memory_order_acquire);
-        if (s1 & 1u) { __builtin_ia32_pause(); continue; }
+        if (s1 & 1u) { cpu_relax(); continue; }
         const std::vector<Edge>* l = nd.list_if(layer);
         size_t n = 0;
         const Edge* p = nullptr;
@@ -321,7 +338,7 @@ void GraphBuilder::read_list(uint32_t id, unsigned layer, std::vector<Edge>& out
 std::vector<Edge>& GraphBuilder::wlist(Node& nd, unsigned layer) const {
     std::vector<Edge>& v = nd.list(layer);
     const size_t cap = (layer == 0 ? 2 * (size_t)p_.max_nb_connection : (size_t)p_.max_nb_connection) + 2;
-    if (v.capacity() < cap) v.reserve(cap);
+    if (v.capacity() < cap) v.reserve(std::max(cap, v.size() + 2));
     return v;
 }
 
@@ -782,7 +799,7 @@ void GraphBuilder::finalize(FlatIndex& out) const {
     out.dumpmode = 1;
     out.max_nb_connection = p_.max_nb_connection;
     out.level_scale = scale_;
-    out.nb_layer = (uint8_t)max_layer_;
+    out.nb_layer = (uint8_t)(dumped_nb_layer_ ? dumped_nb_layer_ : max_layer_);
     out.ef_construction = p_.ef_construction;
     out.dimension = d_;
     out.dist = p_.dist;

@@ -110,6 +110,7 @@ private:
     BuildParams p_;
     uint64_t n_ = 0, d_ = 0;
     unsigned max_layer_;
+    unsigned dumped_nb_layer_ = 0;  // a reloaded index: the nb_layer of its dump (the level generator then uses NB_LAYER_MAX)
     double scale_;
     uint64_t rng_state_ = 397;
     mutable std::vector<std::unique_ptr<Node[]>> chunks_;

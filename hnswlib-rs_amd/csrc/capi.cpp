@@ -1,5 +1,6 @@
 // capi.cpp -- the C ABI declared in include/hnsw_mi355x.h: the thin hnswgpu_* entry points and the
 // name/layout-compatible replacements of the reference's own f32 FFI (src/libext.rs).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -25,6 +26,16 @@ static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+// worker threads of one call: whatever was spawned is joined when this goes out of scope -- also when a later spawn throws,
+// so that no joinable std::thread is ever destroyed (that would be std::terminate, past every guard)
+struct JoinAll {
+    std::vector<std::thread> th;
+    template <class F> void spawn(F&& f) { th.emplace_back(std::forward<F>(f)); }
+    ~JoinAll() {
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+    }
+};
 // a call that SUCCEEDED with something worth telling (hnswgpu_last_error() returns it until the next failure or note)
 static void note(const std::string& msg) { g_last_error = msg; }
 // No C++ exception may cross the C ABI (the host may be Rust, Julia or C): every entry point runs inside this guard.
@@ -417,9 +428,72 @@ int hnswgpu_search_batch_filtered(const hnswgpu_index* cidx, const float* querie
     CAPI_GUARD_END(HNSWGPU_ERR_ARG)
 }
 
+// Replicas on every device of devices[0..n): the missing ones are uploaded AT THE SAME TIME, one host thread per device
+// (an upload is a host-side re-layout plus ~0.65 GB over PCIe for BASELINE config 2: eight of them one after the other
+// was the first-call cost of an 8-GPU host).  Exclusive lock held.
+static int ensure_devices(hnswgpu_index* idx, const int* devices, int n) {
+    const FlatIndex* f = idx->get_flat();
+    if (!f || f->n == 0) return fail(HNSWGPU_ERR_EMPTY, "index is empty");
+    if (idx->dev_stale) {  // the graph changed: every replica is out of date
+        idx->replicas.clear();
+        idx->dev_stale = false;
+    }
+    std::vector<int> missing;
+    for (int s = 0; s < n; ++s)
+        if (!idx->replica(devices[s]) && std::find(missing.begin(), missing.end(), devices[s]) == missing.end()) missing.push_back(devices[s]);
+    if (!missing.empty()) {
+        std::vector<std::unique_ptr<DeviceIndex>> fresh(missing.size());
+        std::vector<int> rcs(missing.size(), OK);
+        std::vector<std::string> errs(missing.size());
+        auto upload_one = [&](size_t i) {
+            try {
+                fresh[i].reset(new DeviceIndex());
+                rcs[i] = fresh[i]->upload(*f, missing[i], errs[i]);
+            } catch (const std::exception& e) {
+                rcs[i] = ERR_DEVICE;
+                errs[i] = e.what();
+            }
+        };
+        {
+            JoinAll th;
+            for (size_t i = 1; i < missing.size(); ++i) th.spawn([&, i]() { upload_one(i); });
+            upload_one(0);
+        }
+        for (size_t i = 0; i < missing.size(); ++i)
+            if (rcs[i] != OK) return fail(rcs[i], "device " + std::to_string(missing[i]) + ": " + errs[i]);
+        for (size_t i = 0; i < missing.size(); ++i) {
+            if (idx->strict_ties >= 0) fresh[i]->set_strict_ties(idx->strict_ties != 0);
+            idx->replicas[missing[i]] = std::move(fresh[i]);
+        }
+    }
+    if (n > 0 && (idx->primary < 0 || !idx->replica(idx->primary))) idx->primary = devices[0];
+    return HNSWGPU_OK;
+}
+
+// shared front of the sharded entry points: argument checks, replicas, then the shared lock for the searches.
+// Returns HNSWGPU_OK with *empty = true when the index holds no point (the answer is "no neighbours").
+static int sharded_prepare(hnswgpu_index* idx, const int* devices, int n_shards, std::shared_lock<std::shared_mutex>& sl,
+                           std::vector<DeviceIndex*>& reps, bool* empty) {
+    *empty = false;
+    {   // replicas on every device named (exclusive: uploads change the handle)
+        std::unique_lock<std::shared_mutex> xl(idx->mu);
+        if (idx->builder ? idx->builder->nb_point() == 0 : (!idx->flat || idx->flat->n == 0)) { *empty = true; return HNSWGPU_OK; }
+        int rc = ensure_devices(idx, devices, n_shards);
+        if (rc != HNSWGPU_OK) return rc;
+    }
+    sl = std::shared_lock<std::shared_mutex>(idx->mu);
+    if (!idx->fresh() || idx->dev_stale) return fail(HNSWGPU_ERR_DEVICE, "index changed while a search was starting");
+    reps.assign((size_t)n_shards, nullptr);
+    for (int s = 0; s < n_shards; ++s) {  // every replica resolved BEFORE the first thread exists
+        reps[(size_t)s] = idx->replica(devices[s]);
+        if (!reps[(size_t)s]) return fail(HNSWGPU_ERR_DEVICE, "replica missing");
+    }
+    return HNSWGPU_OK;
+}
+
 // Hnsw::parallel_search with the batch sharded over several GPUs of this process: graph replicated (one replica per
-// distinct device, uploaded on first use), contiguous balanced blocks of queries, one host thread per shard, every shard
-// copies its answers straight into the caller's arrays -- the gather.  No collective: the shards are independent.
+// distinct device, uploaded on first use, all at once), contiguous balanced blocks of queries, one host thread per shard,
+// every shard copies its answers straight into the caller's arrays -- the gather.  No collective: the shards are independent.
 int hnswgpu_search_batch_sharded(const hnswgpu_index* cidx, const int* devices, int n_shards, const float* queries, uint64_t nq,
                                  uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dists, uint8_t* out_layer,
                                  int32_t* out_rank, uint32_t* out_counts) {
@@ -427,44 +501,81 @@ int hnswgpu_search_batch_sharded(const hnswgpu_index* cidx, const int* devices, 
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx || !devices || n_shards <= 0) return fail(HNSWGPU_ERR_ARG, "bad argument");
     if (nq && (!queries || !out_ids || !out_dists || !out_counts)) return fail(HNSWGPU_ERR_ARG, "null buffer");
-    {   // replicas on every device named (exclusive: uploads change the handle)
-        std::unique_lock<std::shared_mutex> xl(idx->mu);
-        const bool empty = idx->builder ? idx->builder->nb_point() == 0 : (!idx->flat || idx->flat->n == 0);
-        if (empty) {
-            if (out_counts) std::memset(out_counts, 0, nq * sizeof(uint32_t));
-            return HNSWGPU_OK;
-        }
-        for (int s = 0; s < n_shards; ++s) {
-            int rc = ensure_device(idx, devices[s]);
-            if (rc != HNSWGPU_OK) return rc;
-        }
+    std::shared_lock<std::shared_mutex> sl;
+    std::vector<DeviceIndex*> reps;
+    bool empty = false;
+    int prc = sharded_prepare(idx, devices, n_shards, sl, reps, &empty);
+    if (prc != HNSWGPU_OK) return prc;
+    if (empty) {
+        if (out_counts) std::memset(out_counts, 0, nq * sizeof(uint32_t));
+        return HNSWGPU_OK;
     }
-    std::shared_lock<std::shared_mutex> sl(idx->mu);
-    if (!idx->fresh() || idx->dev_stale) return fail(HNSWGPU_ERR_DEVICE, "index changed while a search was starting");
     std::vector<int> rcs((size_t)n_shards, OK);
     std::vector<std::string> errs((size_t)n_shards);
-    std::vector<std::thread> th;
-    const uint64_t base = nq / (uint64_t)n_shards, rem = nq % (uint64_t)n_shards;  // shard s: base + (s < rem) queries
-    uint64_t start = 0;
-    for (int s = 0; s < n_shards; ++s) {
-        const uint64_t cnt = base + ((uint64_t)s < rem ? 1 : 0);
-        DeviceIndex* dev = idx->replica(devices[s]);
-        if (!dev) return fail(HNSWGPU_ERR_DEVICE, "replica missing");
-        const uint64_t s0 = start;
-        start += cnt;
-        if (cnt == 0) continue;
-        th.emplace_back([=, &rcs, &errs]() {
-            try {
-                rcs[(size_t)s] = dev->search_host(queries + s0 * d, cnt, d, k, ef, out_ids + s0 * k, out_dists + s0 * k,
-                                                  out_layer ? out_layer + s0 * k : nullptr, out_rank ? out_rank + s0 * k : nullptr,
-                                                  out_counts + s0, nullptr, 0, false, nullptr, nullptr, errs[(size_t)s]);
-            } catch (const std::exception& e) {
-                rcs[(size_t)s] = ERR_DEVICE;
-                errs[(size_t)s] = e.what();
-            }
-        });
+    {
+        JoinAll th;  // joins whatever was spawned, also when a spawn throws
+        const uint64_t base = nq / (uint64_t)n_shards, rem = nq % (uint64_t)n_shards;  // shard s: base + (s < rem) queries
+        uint64_t start = 0;
+        for (int s = 0; s < n_shards; ++s) {
+            const uint64_t cnt = base + ((uint64_t)s < rem ? 1 : 0);
+            DeviceIndex* dev = reps[(size_t)s];
+            const uint64_t s0 = start;
+            start += cnt;
+            if (cnt == 0) continue;
+            th.spawn([=, &rcs, &errs]() {
+                try {
+                    rcs[(size_t)s] = dev->search_host(queries + s0 * d, cnt, d, k, ef, out_ids + s0 * k, out_dists + s0 * k,
+                                                      out_layer ? out_layer + s0 * k : nullptr, out_rank ? out_rank + s0 * k : nullptr,
+                                                      out_counts + s0, nullptr, 0, false, nullptr, nullptr, errs[(size_t)s]);
+                } catch (const std::exception& e) {
+                    rcs[(size_t)s] = ERR_DEVICE;
+                    errs[(size_t)s] = e.what();
+                }
+            });
+        }
     }
-    for (auto& t : th) t.join();
+    for (int s = 0; s < n_shards; ++s)
+        if (rcs[(size_t)s] != OK) return fail(rcs[(size_t)s], "shard " + std::to_string(s) + ": " + errs[(size_t)s]);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
+int hnswgpu_search_batch_sharded_device(const hnswgpu_index* cidx, const int* devices, int n_shards, const float* const* d_queries,
+                                        const uint64_t* nq_shard, uint64_t d, uint64_t k, uint64_t ef, uint64_t* const* d_out_ids,
+                                        float* const* d_out_dists, uint8_t* const* d_out_layer, int32_t* const* d_out_rank,
+                                        uint32_t* const* d_out_counts, void* const* streams) {
+    CAPI_GUARD_BEGIN
+    hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
+    if (!idx || !devices || n_shards <= 0 || !nq_shard || !d_queries || !d_out_ids || !d_out_dists || !d_out_counts)
+        return fail(HNSWGPU_ERR_ARG, "bad argument");
+    for (int s = 0; s < n_shards; ++s)
+        if (nq_shard[s] && (!d_queries[s] || !d_out_ids[s] || !d_out_dists[s] || !d_out_counts[s])) return fail(HNSWGPU_ERR_ARG, "null buffer");
+    std::shared_lock<std::shared_mutex> sl;
+    std::vector<DeviceIndex*> reps;
+    bool empty = false;
+    int prc = sharded_prepare(idx, devices, n_shards, sl, reps, &empty);
+    if (prc != HNSWGPU_OK) return prc;
+    if (empty) return fail(HNSWGPU_ERR_EMPTY, "index is empty");  // (device-resident counters cannot be zeroed from here without a device)
+    std::vector<int> rcs((size_t)n_shards, OK);
+    std::vector<std::string> errs((size_t)n_shards);
+    {
+        JoinAll th;
+        for (int s = 0; s < n_shards; ++s) {
+            if (nq_shard[s] == 0) continue;
+            DeviceIndex* dev = reps[(size_t)s];
+            th.spawn([=, &rcs, &errs]() {
+                try {
+                    rcs[(size_t)s] = dev->search_device(d_queries[s], nq_shard[s], d, k, ef, d_out_ids[s], d_out_dists[s],
+                                                        d_out_layer ? d_out_layer[s] : nullptr, d_out_rank ? d_out_rank[s] : nullptr,
+                                                        d_out_counts[s], nullptr, streams ? streams[s] : nullptr, nullptr, 0, nullptr,
+                                                        errs[(size_t)s]);
+                } catch (const std::exception& e) {
+                    rcs[(size_t)s] = ERR_DEVICE;
+                    errs[(size_t)s] = e.what();
+                }
+            });
+        }
+    }
     for (int s = 0; s < n_shards; ++s)
         if (rcs[(size_t)s] != OK) return fail(rcs[(size_t)s], "shard " + std::to_string(s) + ": " + errs[(size_t)s]);
     return HNSWGPU_OK;

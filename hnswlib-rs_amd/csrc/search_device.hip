@@ -306,11 +306,13 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     HIP_TRY(hipMalloc(&d_origin_, n * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(d_origin_, x.origin_id.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
     bytes_ += n * sizeof(uint64_t);
-    if (x.dist == DIST_COSINE) {  // DistCosine's per-point sum of squares, once
-        HIP_TRY(hipMalloc(&d_nrm2_, n * sizeof(double)));
-        HIP_TRY(launch_row_sq_norms(nullptr, static_cast<const float*>(d_vec_), static_cast<double*>(d_nrm2_), (uint32_t)n, v.row_stride));
+    if (x.dist == DIST_COSINE) {  // DistCosine's per-point sum of squares, once: inside the row when its padding has room
+        if (!norm_fits_row(x.dist, v.d, v.row_stride)) {
+            HIP_TRY(hipMalloc(&d_nrm2_, n * sizeof(double)));
+            bytes_ += n * sizeof(double);
+        }
+        HIP_TRY(launch_row_sq_norms(nullptr, static_cast<float*>(d_vec_), static_cast<double*>(d_nrm2_), (uint32_t)n, v.d, v.row_stride));
         HIP_TRY(hipDeviceSynchronize());
-        bytes_ += n * sizeof(double);
     }
 
     v.vec = static_cast<const float*>(d_vec_);
@@ -410,6 +412,13 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     Lease lease(this, acquire(err));
     if (!lease.get()) return ERR_DEVICE;
     Workspace& w = *lease.get();
+    // an error return may leave kernels of this call running on the stream: they are waited for BEFORE the workspace goes
+    // back to the pool (declared after the lease, destroyed before it)
+    struct DrainOnError {
+        hipStream_t s;
+        bool done = false;
+        ~DrainOnError() { if (!done) (void)hipStreamSynchronize(s); }
+    } drain{stream};
 
     HIP_TRY(w.qpad.ensure(nq * v_.row_stride * sizeof(float)));
     if (!d_stats) HIP_TRY(w.stats.ensure(nq * 8 * sizeof(uint32_t)));
@@ -446,6 +455,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         info.main_ms = ms_main;
         info.launches = 1;
         publish();
+        drain.done = true;
         return OK;
     }
 
@@ -624,6 +634,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     info.main_ms = ms_main;
     info.launches = launches;
     publish();
+    drain.done = true;
     return OK;
 }
 
@@ -731,8 +742,8 @@ public:
         HIP_TRY(level_.ensure(n));
         HIP_TRY(hipMemcpy(level_.p, levels, n, hipMemcpyHostToDevice));
         if (dist == DIST_COSINE) {
-            HIP_TRY(nrm2_.ensure(n * sizeof(double)));
-            HIP_TRY(launch_row_sq_norms(nullptr, vec_.as<float>(), nrm2_.as<double>(), (uint32_t)n, row_stride_));
+            if (!norm_fits_row(dist, (uint32_t)d, row_stride_)) HIP_TRY(nrm2_.ensure(n * sizeof(double)));
+            HIP_TRY(launch_row_sq_norms(nullptr, vec_.as<float>(), nrm2_.as<double>(), (uint32_t)n, (uint32_t)d, row_stride_));
         }
         // neighbour lists: layer 0 holds up to 2M ids, the others up to M
         bl_ = BuildLists{};
@@ -887,15 +898,15 @@ int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, con
     HIP_TRY(dout.ensure(n_out * sizeof(float)));
     HIP_TRY(hipMemcpy(dq.p, pq.data(), pq.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dr.p, pr.data(), pr.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (dist == DIST_COSINE) {
-        HIP_TRY(dn.ensure(n * sizeof(double)));
-        HIP_TRY(launch_row_sq_norms(nullptr, dr.as<float>(), dn.as<double>(), (uint32_t)n, rs));
+    if (dist == DIST_COSINE) {  // the layout the search uses for this dimension: norm in the row, or beside it
+        if (!norm_fits_row(dist, (uint32_t)d, rs)) HIP_TRY(dn.ensure(n * sizeof(double)));
+        HIP_TRY(launch_row_sq_norms(nullptr, dr.as<float>(), dn.as<double>(), (uint32_t)n, (uint32_t)d, rs));
     }
     if (pairs) {
         for (uint64_t q0 = 0; q0 < n; q0 += 32768) {  // gridDim.y is limited to 65535
             const uint32_t cnt = (uint32_t)std::min<uint64_t>(32768, n - q0);
             HIP_TRY(kernel_set(dist).launch_eval_matrix(nullptr, dq.as<float>() + q0 * rs, cnt, dr.as<float>() + q0 * rs, cnt,
-                                                        dist == DIST_COSINE ? dn.as<double>() + q0 : nullptr, dout.as<float>() + q0, rs, 1, true));
+                                                        dn.p ? dn.as<double>() + q0 : nullptr, dout.as<float>() + q0, rs, 1, true));
         }
     } else {
         HIP_TRY(kernel_set(dist).launch_eval_matrix(nullptr, dq.as<float>(), (uint32_t)nq, dr.as<float>(), (uint32_t)n, dn.as<double>(),

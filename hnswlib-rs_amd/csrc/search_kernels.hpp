@@ -43,7 +43,8 @@ struct SearchArgs {
     uint32_t exact_first;   // strict ties, test hook: literal candidate heap from the first pop on
     hent_t* oplog;          // strict ties: [gridDim.x][oplog_cap] per-workgroup log of heap operations
     uint32_t oplog_cap;
-    const double* nrm2;     // DistCosine: [n] squared norm of every point (f64 left-to-right sum of f32 squares)
+    const double* nrm2;     // DistCosine: [n] squared norm of every point (f64 left-to-right sum of f32 squares); nullptr: the
+                            // norm sits in the last 8 bytes of every row's padding (norm_fits_row)
     uint64_t* out_ids;
     float* out_dists;
     uint8_t* out_layer;
@@ -88,7 +89,7 @@ struct BuildArgs {
     uint32_t* out_n;          // [slots]
     uint32_t* hit_ids;        // [count][NB_LAYER_MAX] ef = 1 result of the layers above the point's level (EMPTY_SLOT: none)
     float* hit_d;
-    const double* nrm2;
+    const double* nrm2;       // DistCosine: as in SearchArgs (nullptr: in the rows)
 };
 
 // Three translation units per metric instantiate the kernels (search_kernels_tu.hip with -DHNSW_THIS_METRIC / -DHNSW_PART:
@@ -136,7 +137,11 @@ template <> const KernelSet& kernels_for<DIST_JEFFREYS>();
 template <> const KernelSet& kernels_for<DIST_JENSENSHANNON>();
 // metric-independent helpers (instantiated once, in part 2 of the L2 units)
 hipError_t launch_allow_bitmap(hipStream_t stream, const uint64_t* origin_id, uint32_t n, const uint64_t* ids, uint64_t m, uint32_t* allow);
-hipError_t launch_row_sq_norms(hipStream_t stream, const float* vec, double* out, uint32_t n, uint32_t row_stride);
+// DistCosine: every point's squared norm (the crate's arithmetic) into out[n] -- or, out == nullptr, into the last 8 bytes of
+// each row's padding (norm_fits_row)
+hipError_t launch_row_sq_norms(hipStream_t stream, float* vec, double* out, uint32_t n, uint32_t d, uint32_t row_stride);
+// a DistCosine row keeps its f64 squared norm inside its own 128-byte-padded row when the padding has two free floats
+inline bool norm_fits_row(int metric, uint32_t d, uint32_t row_stride) { return metric == DIST_COSINE && row_stride >= d + 2u; }
 hipError_t launch_scatter_lists(hipStream_t stream, const uint32_t* upd, uint32_t n_upd, uint32_t rec_words, const BuildLists& lists);
 
 }  // namespace hnswgpu

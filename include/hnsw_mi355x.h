@@ -196,6 +196,15 @@ int hnswgpu_search_batch_filtered(const hnswgpu_index* idx, const float* queries
 int hnswgpu_search_batch_sharded(const hnswgpu_index* idx, const int* devices, int n_shards, const float* queries,
                                  uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids, float* out_dists,
                                  uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts);
+/* The same for a host that already holds its data in HBM: shard s searches nq_shard[s] queries that sit at d_queries[s] ON
+ * devices[s] and leaves its answers in that device's d_out_*[s] arrays (nq_shard[s] x k; d_out_layer / d_out_rank and their
+ * entries may be NULL) -- no PCIe traffic but the counters.  One host thread per shard; streams[s] (hipStream_t as void*,
+ * may be NULL, the array too) is the stream shard s launches on.  Missing replicas are uploaded first, all devices at once.
+ * What is exchanged afterwards (answers only: nq x k x 12 bytes) is the caller's collective, e.g. RCCL all-gather.         */
+int hnswgpu_search_batch_sharded_device(const hnswgpu_index* idx, const int* devices, int n_shards, const float* const* d_queries,
+                                        const uint64_t* nq_shard, uint64_t d, uint64_t k, uint64_t ef, uint64_t* const* d_out_ids,
+                                        float* const* d_out_dists, uint8_t* const* d_out_layer, int32_t* const* d_out_rank,
+                                        uint32_t* const* d_out_counts, void* const* streams);
 
 /* Same with every buffer already resident in HBM (device pointers), launched on HIP stream
  * `stream` (hipStream_t as void*; NULL = default stream).  Synchronises `stream` once

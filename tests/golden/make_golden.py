@@ -30,6 +30,11 @@ CASES = {
     "hell_d12": (180, 12, 8, 30, "DistHellinger", "prob", 8, 24, 24),
     "jeff_d12": (180, 12, 8, 30, "DistJeffreys", "prob", 8, 24, 24),
     "js_d12": (180, 12, 8, 30, "DistJensenShannon", "prob", 8, 24, 24),
+    # tie-saturated data: what these pin, the day oracle/ref_pin runs, is the ORDER of std's BinaryHeap among equal
+    # distances (pop order, "pop when len > ef", into_sorted_vec), not only tie-free arithmetic
+    "l2_dup_d16": (300, 16, 8, 40, "DistL2", "dup", 10, 32, 40),     # every vector stored three times under distinct ids
+    "l1_grid_d4": (256, 4, 6, 30, "DistL1", "grid", 10, 24, 40),     # small-integer grid (tests/filtertest.rs:229-241): integer L1 distances
+    "l2_ef100_d32": (400, 32, 12, 60, "DistL2", False, 100, 100, 16),  # ef > 64 (two result slots per lane), k = ef: all of return_points, sorted
 }
 
 
@@ -38,12 +43,18 @@ def main():
         rng = np.random.default_rng(abs(hash(name)) % (1 << 31) if False else sum(map(ord, name)))
         X = rng.random((n, d), dtype=np.float32)
         Q = rng.random((nq, d), dtype=np.float32)
+        if normalize == "dup":      # n / 3 distinct vectors, each three times; half of the queries ARE stored vectors
+            X = np.ascontiguousarray(np.tile(X[: n // 3], (3, 1)))[rng.permutation(n)]
+            Q[::2] = X[rng.choice(n, len(Q[::2]), replace=False)]
+        elif normalize == "grid":   # coordinates in {0, 1, 2, 3}: every distance is a small integer, ties everywhere
+            X = rng.integers(0, 4, (n, d)).astype(np.float32)
+            Q = rng.integers(0, 4, (nq, d)).astype(np.float32)
         if normalize == "prob":   # probability vectors (with exact zeros)
             for a in (X, Q):
                 a += np.float32(1e-3)
                 a[:, ::5] = 0.0
                 a /= a.sum(1, dtype=np.float32)[:, None]
-        elif normalize:
+        elif normalize is True:
             for a in (X, Q):
                 for i in range(a.shape[0]):
                     oracle_lib.lib().orc_l2_normalize(a[i].ctypes.data, d)

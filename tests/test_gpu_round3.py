@@ -41,3 +41,138 @@ def test_bench_gpus_2_as_a_plain_command_gathers_the_one_gpu_answers(tmp_path):
     assert np.array_equal(one["counts"], two["counts"])
     assert np.array_equal(one["ids"], two["ids"])
     assert np.array_equal(one["dists"].view(np.uint32), two["dists"].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------- full size
+from test_gpu_parity import assert_same  # noqa: E402
+from test_gpu_round2 import _clustered  # noqa: E402
+
+
+def _full_size(native, oracle, tmp_path, monkeypatch, n, d, m, efc, dist, k, ef, nq, n_dup, n_small_table, normalize=False):
+    """BASELINE config at its REAL size: GPU-assisted build (the product's) -> hnswio dump -> product reload + upload and
+    oracle reload of the same files -> the same queries through both: ids, f32 distance bits, p_ids, counts identical --
+    strict as shipped, then with every pop taken from the literal candidate heap, then with a visited table far too small."""
+    X = _clustered(n, d, 0x5EED0001)
+    if normalize:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    if n_dup:  # exact duplicates (distinct ids): queries near them meet equal f32 distances for certain
+        rng = np.random.default_rng(3)
+        X[rng.choice(n, n_dup, replace=False)] = X[rng.choice(n, n_dup, replace=False)]
+    hb = native.Hnsw(m, n, 16, efc, dist)
+    hb.set_build_options(nthreads=0, gpu_device=0, gpu_window=0)
+    hb.parallel_insert(X)
+    assert hb.get_nb_point() == n
+    hb.file_dump(tmp_path, "full")
+    del hb
+    h = native.HnswIo(tmp_path, "full").load_hnsw(dist)
+    h.upload(0)
+    o = oracle.OracleHnsw.load(tmp_path, "full", dist)
+    Q = _clustered(nq, d, 0x5EED0002)
+    if normalize:
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    Q[:200] = X[np.random.default_rng(4).choice(n, 200, replace=False)]  # 200 queries ARE points
+    ref = o.parallel_search(Q, k, ef)
+    res = h.parallel_search_flat(Q, k, ef)
+    assert_same(res, ref)
+    ties = h.last_tie_count()
+    monkeypatch.setenv("HNSWGPU_EXACT_FIRST", "1")
+    assert_same(h.parallel_search_flat(Q, k, ef), ref)
+    monkeypatch.delenv("HNSWGPU_EXACT_FIRST")
+    monkeypatch.setenv("HNSWGPU_HASH_BITS", "8")
+    s = n_small_table
+    assert_same(h.parallel_search_flat(Q[:s], k, ef), oracle.SearchResult(ref.ids[:s], ref.dists[:s], ref.layers[:s], ref.ranks[:s], ref.counts[:s]))
+    monkeypatch.delenv("HNSWGPU_HASH_BITS")
+    return ties
+
+
+def test_full_size_parity_config2_1m_x_128(native, oracle, tmp_path, monkeypatch):
+    """BASELINE config 2 itself: 1M x 128 L2, M=16, ef_c=200, ef=64, 10 000 clustered queries (20 id bits, 125-KB bitmap slices)."""
+    ties = _full_size(native, oracle, tmp_path, monkeypatch, 1_000_000, 128, 16, 200, "DistL2", 10, 64, 10_000, 2000, 1500)
+    assert ties > 0
+
+
+def test_full_size_parity_config3_cosine_1m2_x_25(native, oracle, tmp_path, monkeypatch):
+    """BASELINE config 3 itself: 1.2M x 25 DistCosine, M=24, ef=128 (two result slots per lane; 21 id bits; every point's f64
+    norm inside its own 128-byte row)."""
+    _full_size(native, oracle, tmp_path, monkeypatch, 1_200_000, 25, 24, 400, "DistCosine", 10, 128, 4000, 2000, 1000)
+
+
+def test_full_size_parity_config3_dot_1m2_x_25(native, oracle, tmp_path, monkeypatch):
+    """Config 3 the way the reference runs it: DistDot on L2-normalised vectors (examples/ann-glove25-angular.rs:81-82, :107-108)."""
+    _full_size(native, oracle, tmp_path, monkeypatch, 1_200_000, 25, 24, 400, "DistDot", 10, 128, 4000, 2000, 1000, normalize=True)
+
+
+# ------------------------------------------------------------------------------------------------- DistCosine: norm inside the row
+@pytest.mark.parametrize("d", [1, 2, 25, 29, 30, 31, 32, 33, 62, 63, 64, 94, 100, 126, 127, 128, 130, 254])
+def test_cosine_norm_in_the_row_or_beside_it(native, oracle, tmp_path, d):
+    """A DistCosine row keeps its f64 squared norm in the last 8 bytes of its 128-byte-padded row when the padding has two
+    free floats (d % 32 in 1..30), else in the side array: both layouts, searched and evaluated, equal the oracle bit for bit.
+    Values include huge / tiny norms whose f64 bit patterns read as f32 are NaN / Inf / denormal in the padding."""
+    rng = np.random.default_rng(100 + d)
+    n = 3000
+    X = rng.random((n, d), dtype=np.float32)
+    X[::7] *= np.float32(1e18)      # norms whose high words look like odd floats
+    X[1::7] *= np.float32(1e-18)
+    X[5] = 0.0                      # a zero vector: DistCosine's 0-norm rule
+    Q = rng.random((300, d), dtype=np.float32)
+    Q[:50] = X[:50]
+    o = oracle.OracleHnsw(12, n, 16, 80, "DistCosine")
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "cos")
+    h = native.HnswIo(tmp_path, "cos").load_hnsw("DistCosine")
+    h.upload(0)
+    assert_same(h.parallel_search_flat(Q, 10, 100), o.parallel_search(Q, 10, 100))
+    got = native.eval_distance_matrix("DistCosine", Q[:8], X[:200], batch=33)
+    want = np.array([[oracle.eval_distance("DistCosine", q, x) for x in X[:200]] for q in Q[:8]], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------- sharded, device-resident
+def test_sharded_device_entry_point_equals_unsharded(native, oracle, tmp_path):
+    """hnswgpu_search_batch_sharded_device: every shard's queries and answers already sit in HBM (here three shards on the
+    box's one device, each with its own stream): the per-shard answers, put side by side, equal the unsharded search and the
+    oracle (BASELINE config 4's partitioning)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(12)
+    n, d, k, ef = 6000, 24, 10, 48
+    X = rng.random((n, d), dtype=np.float32)
+    Q = rng.random((1001, d), dtype=np.float32)
+    o = oracle.OracleHnsw(12, n, 16, 80, "DistL2")
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "sh")
+    h = native.HnswIo(tmp_path, "sh").load_hnsw("DistL2")
+    lib = native.lib()
+    dev = torch.device("cuda", 0)
+    sizes = [334, 334, 333]
+    bounds = np.cumsum([0] + sizes)
+    qs = [torch.from_numpy(Q[bounds[s]:bounds[s + 1]]).to(dev) for s in range(3)]
+    ids = [torch.zeros((sizes[s], k), dtype=torch.int64, device=dev) for s in range(3)]
+    dists = [torch.zeros((sizes[s], k), dtype=torch.float32, device=dev) for s in range(3)]
+    layers = [torch.zeros((sizes[s], k), dtype=torch.uint8, device=dev) for s in range(3)]
+    ranks = [torch.zeros((sizes[s], k), dtype=torch.int32, device=dev) for s in range(3)]
+    counts = [torch.zeros((sizes[s],), dtype=torch.int32, device=dev) for s in range(3)]
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    torch.cuda.synchronize(dev)
+
+    def ptrs(ts):
+        return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+
+    devices = (C.c_int * 3)(0, 0, 0)
+    nqs = (C.c_uint64 * 3)(*sizes)
+    rc = lib.hnswgpu_search_batch_sharded_device(h.handle, devices, 3, ptrs(qs), nqs, d, k, ef, ptrs(ids), ptrs(dists), ptrs(layers),
+                                                 ptrs(ranks), ptrs(counts), (C.c_void_p * 3)(*[s.cuda_stream for s in streams]))
+    assert rc == 0, native._native.last_error()
+    torch.cuda.synchronize(dev)
+    got = oracle.SearchResult(torch.cat(ids).cpu().numpy().astype(np.uint64), torch.cat(dists).cpu().numpy(), torch.cat(layers).cpu().numpy(),
+                              torch.cat(ranks).cpu().numpy(), torch.cat(counts).cpu().numpy().astype(np.uint32))
+    ref = o.parallel_search(Q, k, ef)
+    assert_same(got, ref)
+    assert_same(h.parallel_search_flat(Q, k, ef), ref)
+    # the caller's current HIP device is what it was (every entry point restores it)
+    assert torch.cuda.current_device() == 0
+    # no layer / rank arrays, default streams
+    rc = lib.hnswgpu_search_batch_sharded_device(h.handle, devices, 3, ptrs(qs), nqs, d, k, ef, ptrs(ids), ptrs(dists), None, None, ptrs(counts), None)
+    assert rc == 0, native._native.last_error()
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(torch.cat(ids).cpu().numpy().astype(np.uint64), ref.ids)

@@ -189,3 +189,9 @@ def test_datamap_serves_vectors_by_id_without_loading_the_graph(native, oracle, 
     open(tmp_path / "bad.hnsw.graph", "wb").write(open(tmp_path / "dm.hnsw.graph", "rb").read())
     with pytest.raises(native.HnswError):
         native.DataMap.from_hnswdump(tmp_path, "bad")
+    # a view outlives every other reference to the DataMap: it keeps the mapping alive (no munmap under it)
+    import gc
+    view = m.get_data(int(ids[5]))
+    del m
+    gc.collect()
+    assert np.array_equal(view, X[5])

@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 O=gpurun_out/${1:-configs}
 mkdir -p $O
-for cfg in sift1m glove25 mnist784 random10k; do
+for cfg in sift1m glove25 glove25_dot mnist784 random10k; do
   timeout 400 python bench.py --config $cfg --steps 20 --warmup 3 > $O/bench_$cfg.json 2> $O/bench_$cfg.log
   echo "== $cfg"; python tools/bench_line.py < $O/bench_$cfg.json
 done
