@@ -180,6 +180,43 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     return cpu_baseline, parity
 
 
+def probe_rccl_on_one_device(n_ranks, seconds=90):
+    """Does RCCL complete a collective with n_ranks ranks on ONE HIP device?  Asked in disposable processes, because its way
+    of refusing may be a hang.  Returns (True, None) or (False, reason)."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    code = ("import datetime, torch, torch.distributed as dist\n"
+            "torch.cuda.set_device(0)\n"
+            "dist.init_process_group('nccl', timeout=datetime.timedelta(seconds=45), device_id=torch.device('cuda', 0))\n"
+            "t = torch.ones(1, device='cuda:0'); dist.all_reduce(t); torch.cuda.synchronize()\n"
+            "assert int(t.item()) == dist.get_world_size()\n"
+            "dist.destroy_process_group()\n")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "rccl_probe.py")
+        with open(script, "w") as f:
+            f.write(code)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr",
+                              "127.0.0.1", "--master-port", str(port), script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                             text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=seconds)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)  # the probe's own process group, nothing else
+            p.communicate()
+            return False, f"RCCL did not complete an all_reduce of {n_ranks} ranks sharing HIP device 0 within {seconds} s (it hangs instead of refusing)"
+        if p.returncode == 0:
+            return True, None
+        lines = [l for l in (out or "").splitlines() if "rror" in l or "Duplicate" in l or "invalid" in l]
+        return False, ("RCCL refused %d ranks on one device: %s" % (n_ranks, (lines[-1] if lines else "exit code %d" % p.returncode)[:240]))
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: this process becomes the launcher -- one rank per GPU through
     torch.distributed.run on this node -- and returns the ranks' exit code.  Rank 0 prints the JSON line."""
@@ -199,6 +236,13 @@ def spawn_ranks(args):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    if args.share_device and args.backend == "nccl":
+        # every rank on ONE device is not a configuration RCCL serves; whether it refuses (or hangs) is found out in throw-away
+        # processes, and only then do the ranks gather over gloo -- the line reports which backend ran and why
+        ok, reason = probe_rccl_on_one_device(args.gpus)
+        if not ok:
+            log(f"--share-device: {reason}; the answers are gathered over gloo")
+            env["HNSW_BENCH_GATHER_FALLBACK"] = reason
     # this command's own arguments travel in the environment: the launcher's option parser would try to claim the ones that
     # look like prefixes of its own options (--n ...)
     env["HNSW_BENCH_ARGV"] = json.dumps(sys.argv[1:])
@@ -206,65 +250,6 @@ def spawn_ranks(args):
            "--master-port", str(port), os.path.abspath(__file__)]
     log(f"--gpus {args.gpus}: launching {args.gpus} ranks ({' '.join(cmd[1:9])} ...)")
     return subprocess.call(cmd, env=env)
-
-
-def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=5):
-    """What a caller pays above the device-buffer call (reported next to `value`, never as `value`):
-    * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (H2D + kernels + D2H);
-    * ffi: the reference's own symbol parallel_search_neighbours_f32 (src/libext.rs:205-254) on a handle loaded the
-      reference's way (get_hnswio + load_hnswdump_f32_<Dist>): array of row pointers in, Vec_api<Neighbourhood_api> out,
-      freed with hnswgpu_free_neighbourhood_vec;
-    * filtered: Hnsw::search_filter with a sorted id vector allowing 1 % / 30 % of the points (literal-heap kernel)."""
-    nq, d = Q.shape
-    out = {}
-
-    def rate(fn, nrep=reps):
-        fn()
-        ts = []
-        for _ in range(nrep):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-        return nq / float(np.median(ts))
-
-    out["host_buffers_queries_per_s"] = round(rate(lambda: index.parallel_search_flat(Q, k, ef)), 1)
-    loader = getattr(lib, "load_hnswdump_f32_" + dist_name, None)
-    if loader is not None:
-        cwd = os.getcwd()
-        os.chdir(cache_dir)  # get_hnswio names a dump in the current directory (src/libext.rs:28-33)
-        try:
-            api = loader(lib.get_hnswio(len(base), base.encode()))
-        finally:
-            os.chdir(cwd)
-        if api:
-            rows = (C.c_void_p * nq)(*[Q.ctypes.data + i * d * 4 for i in range(nq)])
-            first = {}
-
-            def ffi_call():
-                v = lib.parallel_search_neighbours_f32(api, nq, d, rows, k, ef)
-                if not v:
-                    raise RuntimeError("parallel_search_neighbours_f32 returned NULL: " + H._native.last_error())
-                if not first:
-                    first["ids0"] = [v.contents.ptr[0].neighbours[j].id for j in range(v.contents.ptr[0].nbgh)]
-                lib.hnswgpu_free_neighbourhood_vec(v)
-
-            out["ffi_parallel_search_neighbours_f32_queries_per_s"] = round(rate(ffi_call), 1)
-            out["ffi_first_answer_ids"] = first.get("ids0")
-            lib.drop_hnsw_f32(api)
-    rng = np.random.default_rng(0xF117)
-    for pct in (1, 30):
-        allowed = np.sort(rng.choice(n, max(1, n * pct // 100), replace=False)).astype(np.uint64)  # origin ids = 0..n-1 here
-        sub = Q[: min(nq, 2000)]
-        t = []
-        index.parallel_search_filter_flat(sub, k, ef, allowed)
-        for _ in range(3):
-            t0 = time.perf_counter()
-            index.parallel_search_filter_flat(sub, k, ef, allowed)
-            t.append(time.perf_counter() - t0)
-        out[f"filtered_{pct}pct_queries_per_s"] = round(sub.shape[0] / float(np.median(t)), 1)
-        out[f"filtered_{pct}pct_kernel_ms"] = round(index.last_kernel_ms()[0], 3)
-    out["filtered_note"] = "2 000 queries per call, host buffers, hnsw_search_exact_kernel (both heaps literal, allow bitmap built per call)"
-    return out
 
 
 def main():
@@ -321,31 +306,13 @@ def main():
         import datetime
         import torch.distributed as dist_pg_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        fallback_reason = None
-        if args.backend == "nccl":
-            try:
-                # backend "nccl" IS RCCL on ROCm; the communicator is created here (device_id), so a refusal shows up now
-                dist_pg_mod.init_process_group("nccl", timeout=datetime.timedelta(minutes=30), device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist_pg_mod.all_reduce(probe)
-                torch.cuda.synchronize(dev)
-            except Exception as e:  # noqa: BLE001
-                # RCCL refuses two ranks on ONE device ("Duplicate GPU detected"): only on a --share-device run of the
-                # multi-rank path is that a reason to gather over gloo instead -- and the line says which backend ran
-                if not args.share_device:
-                    raise
-                fallback_reason = f"{type(e).__name__}: {str(e).splitlines()[0][:200]}"
-                log(f"rank {rank}: RCCL refused the shared device ({fallback_reason}); gathering over gloo")
-                try:
-                    if dist_pg_mod.is_initialized():
-                        dist_pg_mod.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend_used = "gloo"
-                port = int(os.environ.get("MASTER_PORT", "29500")) + 1
-                dist_pg_mod.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
-                                               timeout=datetime.timedelta(hours=2))
+        fallback_reason = os.environ.get("HNSW_BENCH_GATHER_FALLBACK") if args.share_device else None
+        if args.backend == "nccl" and fallback_reason is None:
+            # backend "nccl" IS RCCL on ROCm; the communicator is created here (device_id)
+            dist_pg_mod.init_process_group("nccl", timeout=datetime.timedelta(minutes=30), device_id=dev)
         else:
+            # gloo: asked for, or the launcher found that RCCL does not serve ranks sharing one device (--share-device only)
+            backend_used = "gloo"
             dist_pg_mod.init_process_group("gloo", timeout=datetime.timedelta(hours=2))
         dist_pg = dist_pg_mod
     coll_dev = dev if backend_used == "nccl" else torch.device("cpu")  # gloo collectives run on host tensors

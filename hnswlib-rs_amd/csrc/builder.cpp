@@ -196,6 +196,8 @@ struct GraphBuilder::Tls {
     std::vector<uint32_t> stamp;
     uint32_t epoch = 0;
     std::vector<Edge> cand_heap, res_heap, nbuf, res, sel, tmp, discarded;
+    double t_select = 0, t_reverse = 0;  // HNSWGPU_BUILD_TIMING: seconds this thread spent in select_neighbours / reverse updates
+    bool timing = false;
     void begin_visit(size_t n) {
         if (stamp.size() < n) stamp.resize(n, 0);
         if (++epoch == 0) {
@@ -600,7 +602,9 @@ void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_
         if (!t.res.empty()) {
             size_t nb_conn = l == 0 ? 2 * p_.max_nb_connection : p_.max_nb_connection;
             bool extend_c = l == 0 ? p_.extend_candidates : false;
+            const auto ts0 = t.timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             select_neighbours(data, t.res, nb_conn, extend_c, (unsigned)l, t, t.sel);
+            if (t.timing) t.t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
             std::stable_sort(t.sel.begin(), t.sel.end(), EdgeLess());  // :1195
             {
                 WriteGuard g(np);
@@ -610,12 +614,14 @@ void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_
         }
     }
     // reverse_update_neighborhood_simple (:1210), remembering which lists of the snapshot are now out of date
+    const auto tr0 = t.timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     for (int l = (int)level; l >= 0; --l) {
         read_list(id, (unsigned)l, t.tmp);
         for (const Edge& q : t.tmp)
             if (q.id != id) dirty.push_back((q.id << 4) | level);
     }
     reverse_update(id, t);
+    if (t.timing) t.t_reverse += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     {   // check_entry_point (src/hnsw.rs:534-557)
         std::lock_guard<std::mutex> g(entry_mutex_);
         if ((int)level > entry_level_.load()) {
@@ -712,7 +718,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
     std::vector<std::vector<uint32_t>> dirty_t((size_t)nthreads);
     // HNSWGPU_BUILD_TIMING=1: where the wall time of the windows goes (stderr, once per call)
     const bool timing = std::getenv("HNSWGPU_BUILD_TIMING") != nullptr;
-    double t_search = 0, t_apply = 0, t_patch = 0;
+    double t_search = 0, t_apply = 0, t_patch = 0, t_select_sum = 0, t_reverse_sum = 0;
     uint64_t n_windows = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (start < n_) {
@@ -731,10 +737,16 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         std::atomic<uint32_t> next{0};
         auto worker = [&](int tid) {
             Tls t;
+            t.timing = timing;
             for (;;) {
                 const uint32_t wi = next.fetch_add(1);
                 if (wi >= count) break;
                 apply_window_point((uint32_t)start + wi, wi, frozen_entry, frozen_level, layer_mask, res, p_.ef_construction, t, dirty_t[(size_t)tid]);
+            }
+            if (timing) {
+                std::lock_guard<std::mutex> g(entry_mutex_);
+                t_select_sum += t.t_select;
+                t_reverse_sum += t.t_reverse;
             }
         };
         const int nt = (int)std::min<uint64_t>((uint64_t)nthreads, std::max<uint32_t>(1, count / 8));
@@ -788,8 +800,9 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
     }
     if (timing)
         std::fprintf(stderr, "[hnswgpu build] %llu windows: device searches %.2f s, host select/reverse-update (%d threads) %.2f s, "
-                             "dirty lists packed + patched on the device %.2f s\n",
-                     (unsigned long long)n_windows, t_search, nthreads, t_apply, t_patch);
+                             "dirty lists packed + patched on the device %.2f s; thread-seconds inside select_neighbours %.2f, inside the "
+                             "reverse updates %.2f\n",
+                     (unsigned long long)n_windows, t_search, nthreads, t_apply, t_patch, t_select_sum, t_reverse_sum);
     return OK;
 }
 

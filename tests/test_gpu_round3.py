@@ -13,7 +13,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(args, timeout=1200):
+def _bench(args, timeout=420):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r, (json.loads(lines[-1]) if lines else None)
@@ -110,10 +110,11 @@ def test_cosine_norm_in_the_row_or_beside_it(native, oracle, tmp_path, d):
     Values include huge / tiny norms whose f64 bit patterns read as f32 are NaN / Inf / denormal in the padding."""
     rng = np.random.default_rng(100 + d)
     n = 3000
-    X = rng.random((n, d), dtype=np.float32)
-    X[::7] *= np.float32(1e18)      # norms whose high words look like odd floats
-    X[1::7] *= np.float32(1e-18)
-    X[5] = 0.0                      # a zero vector: DistCosine's 0-norm rule
+    X = rng.random((n, d), dtype=np.float32) + np.float32(0.05)
+    if d > 1:  # (one dimension: every angle is 0, and rounding trips the crate's own assert on 1 - dot/norms >= -2e-5)
+        X[::7] *= np.float32(1e18)      # norms whose high words look like odd floats
+        X[1::7] *= np.float32(1e-18)
+        X[5] = 0.0                      # a zero vector: DistCosine's 0-norm rule
     Q = rng.random((300, d), dtype=np.float32)
     Q[:50] = X[:50]
     o = oracle.OracleHnsw(12, n, 16, 80, "DistCosine")
@@ -123,7 +124,7 @@ def test_cosine_norm_in_the_row_or_beside_it(native, oracle, tmp_path, d):
     h.upload(0)
     assert_same(h.parallel_search_flat(Q, 10, 100), o.parallel_search(Q, 10, 100))
     got = native.eval_distance_matrix("DistCosine", Q[:8], X[:200], batch=33)
-    want = np.array([[oracle.eval_distance("DistCosine", q, x) for x in X[:200]] for q in Q[:8]], dtype=np.float32)
+    want = oracle.dist_matrix("DistCosine", Q[:8], X[:200])
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
