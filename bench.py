@@ -213,7 +213,8 @@ def probe_rccl_on_one_device(n_ranks, seconds=90):
             return False, f"RCCL did not complete an all_reduce of {n_ranks} ranks sharing HIP device 0 within {seconds} s (it hangs instead of refusing)"
         if p.returncode == 0:
             return True, None
-        lines = [l for l in (out or "").splitlines() if "rror" in l or "Duplicate" in l or "invalid" in l]
+        lines = [l.strip() for l in (out or "").splitlines() if "Duplicate GPU" in l or "NCCL" in l or "ncclInvalid" in l or "invalid usage" in l]
+        lines = lines or [l.strip() for l in (out or "").splitlines() if "Error" in l and "traceback" not in l]
         return False, ("RCCL refused %d ranks on one device: %s" % (n_ranks, (lines[-1] if lines else "exit code %d" % p.returncode)[:240]))
 
 

@@ -887,28 +887,79 @@ const Neighbourhood_api* search_neighbours_f32(const HnswApif32* api, size_t len
     CAPI_GUARD_END(nullptr)
 }
 
+// The answer of parallel_search_neighbours_f32 is ONE allocation: a header, the Vec_api, its nb_vec Neighbourhood_api and every
+// Neighbour_api row behind them (the reference leaks 1 + nb_vec vectors per call, src/libext.rs:236-253; a caller that frees
+// hands the Vec_api pointer to hnswgpu_free_neighbourhood_vec, which finds the header in front of it).
+namespace {
+constexpr uint64_t SLAB_MAGIC = 0x486E7377536C6162ull;  // "HnswSlab"
+struct SlabHeader {
+    uint64_t magic;
+    uint64_t bytes;
+};
+struct FfiAnswer {
+    size_t nq, k;
+    Vec_api_Neighbourhood* out;
+};
+}  // namespace
+
 const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* api, size_t nb_vec, int64_t vec_len,
                                                             const float** data, size_t knbn, size_t ef_search) {
     CAPI_GUARD_BEGIN
     if (!api || !api->idx || !data || knbn == 0 || vec_len <= 0) return nullptr;
-    // array-of-pointers input is copied into one matrix (the reference copies into Vec<Vec<f32>>, :218-226)
-    std::vector<float> q((size_t)nb_vec * (size_t)vec_len);
-    for (size_t i = 0; i < nb_vec; ++i) std::memcpy(q.data() + i * (size_t)vec_len, data[i], (size_t)vec_len * sizeof(float));
-    std::vector<uint64_t> ids(nb_vec * knbn);
-    std::vector<float> dists(nb_vec * knbn);
-    std::vector<uint32_t> cnt(nb_vec);
-    if (hnswgpu_search_batch(api->idx, q.data(), nb_vec, (uint64_t)vec_len, knbn, ef_search, ids.data(), dists.data(), nullptr,
-                             nullptr, cnt.data()) != HNSWGPU_OK)
-        return nullptr;
-    Neighbourhood_api* lists = static_cast<Neighbourhood_api*>(std::malloc(std::max<size_t>(1, nb_vec) * sizeof(Neighbourhood_api)));
-    for (size_t i = 0; i < nb_vec; ++i) {
-        lists[i].nbgh = cnt[i];
-        lists[i].neighbours = make_row(ids.data() + i * knbn, dists.data() + i * knbn, cnt[i]);
+    hnswgpu_index* idx = api->idx;
+    FfiAnswer ans{nb_vec, knbn, nullptr};
+    // the row pointers are gathered straight into pinned staging memory (the reference copies them into Vec<Vec<f32>>,
+    // :218-226), the answers are unpacked straight out of it into the slab
+    auto sink = [](void* ctx, const DeviceIndex::HostAnswers& a) {
+        FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
+        const size_t bytes = sizeof(SlabHeader) + sizeof(Vec_api_Neighbourhood) + f.nq * sizeof(Neighbourhood_api) +
+                             f.nq * f.k * sizeof(Neighbour_api);
+        unsigned char* slab = static_cast<unsigned char*>(std::malloc(bytes));
+        if (!slab) return;
+        SlabHeader* h = reinterpret_cast<SlabHeader*>(slab);
+        h->magic = SLAB_MAGIC;
+        h->bytes = bytes;
+        Vec_api_Neighbourhood* v = reinterpret_cast<Vec_api_Neighbourhood*>(slab + sizeof(SlabHeader));
+        Neighbourhood_api* lists = reinterpret_cast<Neighbourhood_api*>(v + 1);
+        Neighbour_api* rows = reinterpret_cast<Neighbour_api*>(lists + f.nq);
+        for (size_t i = 0; i < f.nq; ++i) {
+            const uint32_t c = a.counts[i];
+            Neighbour_api* r = rows + i * f.k;
+            for (uint32_t j = 0; j < c; ++j) {
+                r[j].id = (size_t)a.ids[i * f.k + j];
+                r[j].d = a.dists[i * f.k + j];
+            }
+            lists[i].nbgh = (int64_t)c;
+            lists[i].neighbours = r;
+        }
+        v->len = (int64_t)f.nq;
+        v->ptr = lists;
+        f.out = v;
+    };
+    std::string err;
+    int rc;
+    {
+        std::shared_lock<std::shared_mutex> sl(idx->mu);
+        const bool empty = idx->builder ? idx->builder->nb_point() == 0 : (!idx->flat || idx->flat->n == 0);
+        if (empty || nb_vec == 0) {  // empty index => every answer is empty (src/hnsw.rs:1498-1503)
+            std::vector<uint32_t> zero(std::max<size_t>(1, nb_vec), 0u);
+            DeviceIndex::HostAnswers a{};
+            a.counts = zero.data();
+            sink(&ans, a);
+            return ans.out;
+        }
+        DeviceIndex* dev = nullptr;
+        rc = primary_replica(idx, sl, &dev);
+        if (rc != HNSWGPU_OK) return nullptr;
+        rc = dev->search_host_staged(nullptr, data, nb_vec, (uint64_t)vec_len, knbn, ef_search, nullptr, 0, false, false, sink, &ans,
+                                     nullptr, err);
     }
-    Vec_api_Neighbourhood* ans = static_cast<Vec_api_Neighbourhood*>(std::malloc(sizeof(Vec_api_Neighbourhood)));
-    ans->len = (int64_t)nb_vec;
-    ans->ptr = lists;
-    return ans;
+    if (rc != OK) {
+        fail(rc, err);
+        return nullptr;
+    }
+    if (!ans.out) fail(HNSWGPU_ERR_ARG, "out of memory");
+    return ans.out;
     CAPI_GUARD_END(nullptr)
 }
 
@@ -919,6 +970,11 @@ void hnswgpu_free_neighbourhood(const Neighbourhood_api* p) {
 }
 void hnswgpu_free_neighbourhood_vec(const Vec_api_Neighbourhood* p) {
     if (!p) return;
+    const SlabHeader* h = reinterpret_cast<const SlabHeader*>(reinterpret_cast<const unsigned char*>(p) - sizeof(SlabHeader));
+    if (h->magic == SLAB_MAGIC) {  // (every Vec_api this library hands out is the head of one slab)
+        std::free(const_cast<SlabHeader*>(h));
+        return;
+    }
     for (int64_t i = 0; i < p->len; ++i) std::free(const_cast<Neighbour_api*>(p->ptr[i].neighbours));
     std::free(const_cast<Neighbourhood_api*>(p->ptr));
     std::free(const_cast<Vec_api_Neighbourhood*>(p));

@@ -68,6 +68,22 @@ public:
                     float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
                     const uint64_t* allowed, uint64_t n_allowed, bool filtered, uint8_t* out_status, CallInfo* info,
                     std::string& err);
+    // What search_host is made of, for callers with other shapes of input / output (the reference's FFI: an array of row
+    // pointers in, per-query vectors out).  Queries come from `queries` (nq x d) or, when that is null, from rows[0..nq);
+    // they are gathered by a few host threads into PINNED staging memory, copied to the device asynchronously, searched, and
+    // the answers come back into pinned memory too; `sink` sees them there (valid only during the call).
+    struct HostAnswers {
+        const uint64_t* ids;      // [nq][k]
+        const float* dists;       // [nq][k]
+        const uint8_t* layer;     // [nq][k]
+        const int32_t* rank;      // [nq][k]
+        const uint32_t* counts;   // [nq]
+        const uint8_t* status;    // [nq] filtered search: 1 = the reference panics on this query (else nullptr)
+    };
+    typedef void (*AnswerSink)(void* ctx, const HostAnswers& a);
+    int search_host_staged(const float* queries, const float* const* rows, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
+                           const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, AnswerSink sink, void* ctx,
+                           CallInfo* info, std::string& err);
 
     // strict ties: decisions that depend on the reference's heap order are resolved with literal heaps
     void set_strict_ties(bool on) { strict_ties_.store(on); }

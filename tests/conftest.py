@@ -17,6 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def native():
     """The product package with its C-ABI library built (cross-compiles without a GPU)."""
+    # PyTorch first where a test also uses it (device tensors, streams): the C-ABI library then binds to the HIP runtime
+    # torch already loaded; the other order leaves torch without a device ("No HIP GPUs are available"; INTEGRATION.md)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import hnsw_rs_amd as H
     H.build_native()
     H.lib()
