@@ -253,6 +253,65 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=5):
+    """What a caller pays above the device-buffer call (reported next to `value`, never as `value`):
+    * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (H2D + kernels + D2H);
+    * ffi: the reference's own symbol parallel_search_neighbours_f32 (src/libext.rs:205-254) on a handle loaded the
+      reference's way (get_hnswio + load_hnswdump_f32_<Dist>): array of row pointers in, Vec_api<Neighbourhood_api> out,
+      freed with hnswgpu_free_neighbourhood_vec;
+    * filtered: Hnsw::search_filter with a sorted id vector allowing 1 % / 30 % of the points (literal-heap kernel)."""
+    nq, d = Q.shape
+    out = {}
+
+    def rate(fn, nrep=reps):
+        fn()
+        ts = []
+        for _ in range(nrep):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return nq / float(np.median(ts))
+
+    out["host_buffers_queries_per_s"] = round(rate(lambda: index.parallel_search_flat(Q, k, ef)), 1)
+    loader = getattr(lib, "load_hnswdump_f32_" + dist_name, None)
+    if loader is not None:
+        cwd = os.getcwd()
+        os.chdir(cache_dir)  # get_hnswio names a dump in the current directory (src/libext.rs:28-33)
+        try:
+            api = loader(lib.get_hnswio(len(base), base.encode()))
+        finally:
+            os.chdir(cwd)
+        if api:
+            rows = (C.c_void_p * nq)(*[Q.ctypes.data + i * d * 4 for i in range(nq)])
+            first = {}
+
+            def ffi_call():
+                v = lib.parallel_search_neighbours_f32(api, nq, d, rows, k, ef)
+                if not v:
+                    raise RuntimeError("parallel_search_neighbours_f32 returned NULL: " + H._native.last_error())
+                if not first:
+                    first["ids0"] = [v.contents.ptr[0].neighbours[j].id for j in range(v.contents.ptr[0].nbgh)]
+                lib.hnswgpu_free_neighbourhood_vec(v)
+
+            out["ffi_parallel_search_neighbours_f32_queries_per_s"] = round(rate(ffi_call), 1)
+            out["ffi_first_answer_ids"] = first.get("ids0")
+            lib.drop_hnsw_f32(api)
+    rng = np.random.default_rng(0xF117)
+    for pct in (1, 30):
+        allowed = np.sort(rng.choice(n, max(1, n * pct // 100), replace=False)).astype(np.uint64)  # origin ids = 0..n-1 here
+        sub = Q[: min(nq, 2000)]
+        t = []
+        index.parallel_search_filter_flat(sub, k, ef, allowed)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            index.parallel_search_filter_flat(sub, k, ef, allowed)
+            t.append(time.perf_counter() - t0)
+        out[f"filtered_{pct}pct_queries_per_s"] = round(sub.shape[0] / float(np.median(t)), 1)
+        out[f"filtered_{pct}pct_kernel_ms"] = round(index.last_kernel_ms()[0], 3)
+    out["filtered_note"] = "2 000 queries per call, host buffers, hnsw_search_exact_kernel (both heaps literal, allow bitmap built per call)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -589,11 +589,19 @@ void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_
     }
     for (int l = (int)level; l >= 0; --l) {  // :1158-1205
         t.res.clear();
+        bool have_sel = false;
         if ((unsigned)l > frozen_entry_level) {
             // a layer above the snapshot's entry point: search_layer finds the entry point alone, if the layer has a point
             // at all (this one counts: generate_new_point pushed it before the search, :516)
             // (the serial reference sees this point in the layer when l is its own level; other empty layers return nothing)
             if ((unsigned)l == level || ((layer_mask >> l) & 1u)) t.res.push_back(Edge{frozen_entry, eval(data, vec(frozen_entry))});
+        } else if (r.selected) {
+            // the device ran select_neighbours for this slot as well (hnsw_build_select_kernel)
+            const size_t slot = (size_t)r.slot0[wi] + (size_t)l;
+            const uint32_t cnt = r.sel_n[slot];
+            t.sel.clear();
+            for (uint32_t j = 0; j < cnt; ++j) t.sel.push_back(Edge{r.sel_ids[slot * r.sel_stride + j], r.sel_d[slot * r.sel_stride + j]});
+            have_sel = cnt > 0;
         } else {
             const size_t slot = (size_t)r.slot0[wi] + (size_t)l;
             const uint32_t cnt = r.out_n[slot];
@@ -605,6 +613,9 @@ void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_
             const auto ts0 = t.timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             select_neighbours(data, t.res, nb_conn, extend_c, (unsigned)l, t, t.sel);
             if (t.timing) t.t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+            have_sel = true;
+        }
+        if (have_sel) {
             std::stable_sort(t.sel.begin(), t.sel.end(), EdgeLess());  // :1195
             {
                 WriteGuard g(np);
@@ -715,6 +726,13 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         if (rc != OK) return finish_on_host(err);
     }
     WindowSearchResults res;
+    // select_neighbours runs on the device too, unless candidates have to be extended from the lists of the graph under
+    // construction (extend_candidates: what a reloaded index asks for at layer 0) -- that stays with the host's lists
+    WindowSelect wsel;
+    wsel.on_device = !p_.extend_candidates && std::getenv("HNSWGPU_HOST_SELECT") == nullptr;
+    wsel.nb_layer0 = (uint32_t)(2 * p_.max_nb_connection);
+    wsel.nb_upper = (uint32_t)p_.max_nb_connection;
+    wsel.keep_pruned = p_.keep_pruned;
     std::vector<std::vector<uint32_t>> dirty_t((size_t)nthreads);
     // HNSWGPU_BUILD_TIMING=1: where the wall time of the windows goes (stderr, once per call)
     const bool timing = std::getenv("HNSWGPU_BUILD_TIMING") != nullptr;
@@ -730,7 +748,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         for (unsigned l = 0; l < NB_LAYER_MAX; ++l)
             if (layer_inserted_[l].load(std::memory_order_acquire) > 0) layer_mask |= 1u << l;
         const double w0 = now();
-        rc = dev.search_window((uint32_t)start, count, frozen_entry, frozen_level, layer_mask, res, err);
+        rc = dev.search_window((uint32_t)start, count, frozen_entry, frozen_level, layer_mask, wsel, res, err);
         if (rc != OK) return finish_on_host(err);
         const double w1 = now();
         for (auto& v : dirty_t) v.clear();

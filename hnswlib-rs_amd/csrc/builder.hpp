@@ -44,6 +44,20 @@ struct WindowSearchResults {
     std::vector<uint32_t> out_n;    // [slots]
     std::vector<uint32_t> hit_ids;  // [count][NB_LAYER_MAX] ef = 1 hit per layer above the point's level (NO_POINT: none)
     std::vector<float> hit_d;
+    // select_neighbours done on the device as well (WindowSelect::on_device): then out_ids / out_d stay empty and every slot
+    // comes back already selected, in selection order
+    bool selected = false;
+    uint32_t sel_stride = 0;
+    std::vector<uint32_t> sel_ids;  // [slots][sel_stride]
+    std::vector<float> sel_d;
+    std::vector<uint32_t> sel_n;    // [slots]
+};
+// what the device needs to run select_neighbours (src/hnsw.rs:1299-1421) itself for the slots of a window
+struct WindowSelect {
+    bool on_device = false;
+    uint32_t nb_layer0 = 0;   // neighbours asked at layer 0 (2 M) ...
+    uint32_t nb_upper = 0;    // ... and above (M)
+    bool keep_pruned = false;
 };
 // The device side of GPU-assisted construction (implemented in search_device.hip; builder.cpp stays free of HIP).
 class BuildSearchBackend {
@@ -61,7 +75,7 @@ public:
     virtual int patch(const std::vector<uint32_t>& records, std::string& err) = 0;
     // layer_mask: bit l set when some inserted point has level exactly l (search_layer returns nothing on other layers)
     virtual int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask,
-                              WindowSearchResults& out, std::string& err) = 0;
+                              const WindowSelect& select, WindowSearchResults& out, std::string& err) = 0;
 };
 
 class GraphBuilder {

@@ -802,7 +802,7 @@ public:
     explicit DeviceBuildBackend(int device) : device_(device) {}
     ~DeviceBuildBackend() override {
         DeviceGuard on_device(device_);
-        for (DevBuf* b : {&vec_, &level_, &nrm2_, &slot0_, &out_ids_, &out_d_, &out_n_, &hit_ids_, &hit_d_, &bitmap_, &upd_}) b->free();
+        for (DevBuf* b : {&vec_, &level_, &nrm2_, &slot0_, &out_ids_, &out_d_, &out_n_, &hit_ids_, &hit_d_, &bitmap_, &upd_, &slot_nb_, &sel_ids_, &sel_d_, &sel_n_}) b->free();
         for (auto& b : lists_) b.free();
         if (d_ctrl_) (void)hipFree(d_ctrl_);
     }
@@ -872,8 +872,8 @@ public:
         HIP_TRY(hipDeviceSynchronize());
         return OK;
     }
-    int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask, WindowSearchResults& out,
-                      std::string& err) override {
+    int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask,
+                      const WindowSelect& select, WindowSearchResults& out, std::string& err) override {
         DeviceGuard on_device(device_);
         HIP_TRY(on_device.status());
         if (entry_level > top_layer_) { err = "internal error: entry point above the snapshot's layers"; return ERR_ARG; }
@@ -943,16 +943,66 @@ public:
         uint32_t ctrl[2] = {0, 0};
         HIP_TRY(hipMemcpy(ctrl, d_ctrl_, 8, hipMemcpyDeviceToHost));
         if (ctrl[1] != 0) { err = "internal error: visited set overflow in the construction search"; return ERR_DEVICE; }
+        out.hit_ids.resize((size_t)count * NB_LAYER_MAX);
+        out.hit_d.resize((size_t)count * NB_LAYER_MAX);
+        HIP_TRY(hipMemcpy(out.hit_ids.data(), hit_ids_.p, (size_t)count * NB_LAYER_MAX * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.hit_d.data(), hit_d_.p, (size_t)count * NB_LAYER_MAX * sizeof(float), hipMemcpyDeviceToHost));
+        out.selected = false;
+        out.sel_stride = 0;
+        const uint32_t sel_stride = std::max(select.nb_layer0, select.nb_upper);
+        if (select.on_device && slots > 0 && sel_stride > 0 && sel_stride <= 0xFFFFu) {
+            // select_neighbours for every slot, on the candidates the searches just left in HBM (hnsw_build_select_kernel): what
+            // comes back over PCIe is the selected lists (<= 2 M entries per slot) instead of ef_construction candidates
+            slot_nb_h_.assign(slots, 0);
+            for (uint32_t i = 0; i < count; ++i) {
+                const uint32_t top = std::min<uint32_t>(levels_h_[i], entry_level);
+                for (uint32_t l = 0; l <= top; ++l) slot_nb_h_[out.slot0[i] + l] = (uint16_t)(l == 0 ? select.nb_layer0 : select.nb_upper);
+            }
+            HIP_TRY(slot_nb_.ensure(slots * sizeof(uint16_t)));
+            HIP_TRY(hipMemcpy(slot_nb_.p, slot_nb_h_.data(), slots * sizeof(uint16_t), hipMemcpyHostToDevice));
+            HIP_TRY(sel_ids_.ensure(slots * sel_stride * sizeof(uint32_t)));
+            HIP_TRY(sel_d_.ensure(slots * sel_stride * sizeof(float)));
+            HIP_TRY(sel_n_.ensure(slots * sizeof(uint32_t)));
+            SelectArgs sa{};
+            sa.vec = vec_.as<float>();
+            sa.row_stride = row_stride_;
+            sa.tile_bytes = a.tile_bytes;
+            sa.nrm2 = nrm2_.as<double>();
+            sa.cand_ids = out_ids_.as<uint32_t>();
+            sa.cand_d = out_d_.as<float>();
+            sa.cand_n = out_n_.as<uint32_t>();
+            sa.ef_c = ef_c_;
+            sa.slot_nb = slot_nb_.as<uint16_t>();
+            sa.n_slots = (uint32_t)slots;
+            sa.sel_stride = sel_stride;
+            sa.keep_pruned = select.keep_pruned ? 1u : 0u;
+            sa.sel_ids = sel_ids_.as<uint32_t>();
+            sa.sel_d = sel_d_.as<float>();
+            sa.sel_n = sel_n_.as<uint32_t>();
+            sa.work_counter = static_cast<uint32_t*>(d_ctrl_);
+            HIP_TRY(hipMemset(d_ctrl_, 0, 8));
+            const size_t sel_lds = a.tile_bytes + IDS_BYTES + (size_t)sel_stride * 8u;
+            const uint32_t sgrid = (uint32_t)std::min<uint64_t>((uint64_t)num_cu_ * 24u, slots);
+            HIP_TRY(ks.launch_build_select(sgrid, sel_lds, nullptr, sa));
+            out.sel_ids.resize(slots * sel_stride);
+            out.sel_d.resize(slots * sel_stride);
+            out.sel_n.resize(slots);
+            HIP_TRY(hipMemcpy(out.sel_ids.data(), sel_ids_.p, slots * sel_stride * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(out.sel_d.data(), sel_d_.p, slots * sel_stride * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(out.sel_n.data(), sel_n_.p, slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            out.out_ids.clear();
+            out.out_d.clear();
+            out.out_n.clear();
+            out.selected = true;
+            out.sel_stride = sel_stride;
+            return OK;
+        }
         out.out_ids.resize(slots * ef_c_);
         out.out_d.resize(slots * ef_c_);
         out.out_n.resize(slots);
-        out.hit_ids.resize((size_t)count * NB_LAYER_MAX);
-        out.hit_d.resize((size_t)count * NB_LAYER_MAX);
         HIP_TRY(hipMemcpy(out.out_ids.data(), out_ids_.p, slots * ef_c_ * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(out.out_d.data(), out_d_.p, slots * ef_c_ * sizeof(float), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(out.out_n.data(), out_n_.p, slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out.hit_ids.data(), hit_ids_.p, (size_t)count * NB_LAYER_MAX * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out.hit_d.data(), hit_d_.p, (size_t)count * NB_LAYER_MAX * sizeof(float), hipMemcpyDeviceToHost));
         return OK;
     }
 
@@ -963,7 +1013,8 @@ private:
     uint64_t n_ = 0;
     uint32_t ef_c_ = 0, row_stride_ = 0, max_window_ = 1, max_stride_ = 0;
     unsigned top_layer_ = 0;
-    DevBuf vec_, level_, nrm2_, slot0_, out_ids_, out_d_, out_n_, hit_ids_, hit_d_, bitmap_, upd_;
+    DevBuf vec_, level_, nrm2_, slot0_, out_ids_, out_d_, out_n_, hit_ids_, hit_d_, bitmap_, upd_, slot_nb_, sel_ids_, sel_d_, sel_n_;
+    std::vector<uint16_t> slot_nb_h_;
     DevBuf lists_[NB_LAYER_MAX];
     BuildLists bl_{};
     void* d_ctrl_ = nullptr;

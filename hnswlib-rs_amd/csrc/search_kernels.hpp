@@ -92,6 +92,26 @@ struct BuildArgs {
     const double* nrm2;       // DistCosine: as in SearchArgs (nullptr: in the rows)
 };
 
+// select_neighbours on the device (hnsw_build_select_kernel): one wavefront per (window point, layer) slot
+struct SelectArgs {
+    const float* vec;         // as BuildArgs
+    uint32_t row_stride;
+    uint32_t tile_bytes;
+    const double* nrm2;
+    uint32_t* cand_ids;       // [slots][ef_c] what the searches of the window found (ascending distance); scratch afterwards
+    const float* cand_d;
+    const uint32_t* cand_n;   // [slots]
+    uint32_t ef_c;
+    const uint16_t* slot_nb;  // [slots] neighbours asked for the slot: 2 M at layer 0, M above (src/hnsw.rs:1170-1176)
+    uint32_t n_slots;
+    uint32_t sel_stride;      // entries per slot in sel_ids / sel_d (>= every slot_nb)
+    uint32_t keep_pruned;
+    uint32_t* sel_ids;        // [slots][sel_stride] the selected neighbours, in selection order
+    float* sel_d;
+    uint32_t* sel_n;          // [slots]
+    uint32_t* work_counter;
+};
+
 // Three translation units per metric instantiate the kernels (search_kernels_tu.hip with -DHNSW_THIS_METRIC / -DHNSW_PART:
 // strict search kernels, lean search kernels, everything else) -- keeps the build parallel and the objects small.
 struct KernelSet {
@@ -113,6 +133,8 @@ struct KernelSet {
     // construction: the searches of insert_slice for a window of points (hnsw_build_search_kernel)
     hipError_t (*launch_build_search)(int slots, uint32_t grid, size_t lds, hipStream_t stream, const BuildArgs& a);
     hipError_t (*build_occupancy)(int slots, size_t lds, int* per_cu);
+    // construction: select_neighbours for every slot of a window (hnsw_build_select_kernel)
+    hipError_t (*launch_build_select)(uint32_t grid, size_t lds, hipStream_t stream, const SelectArgs& a);
 };
 // merge_list (the accept rule for a whole neighbour list at once) is used up to this many result slots per lane; the launch
 // gets 64 S + 64 LDS entries for its scatter

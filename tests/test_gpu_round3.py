@@ -177,3 +177,32 @@ def test_sharded_device_entry_point_equals_unsharded(native, oracle, tmp_path):
     assert rc == 0, native._native.last_error()
     torch.cuda.synchronize(dev)
     assert np.array_equal(torch.cat(ids).cpu().numpy().astype(np.uint64), ref.ids)
+
+
+# ------------------------------------------------------------------------------------------------- construction: select on the device
+@pytest.mark.parametrize("dist,d,m,efc,extend,keep", [
+    ("DistL2", 16, 12, 60, False, False), ("DistL2", 8, 6, 40, False, True), ("DistL2", 8, 6, 40, True, False),
+    ("DistCosine", 25, 8, 100, False, False), ("DistCosine", 33, 8, 60, False, True), ("DistL1", 10, 10, 40, False, False),
+    ("DistDot", 12, 6, 250, False, False), ("DistJeffreys", 12, 8, 40, False, False), ("DistJensenShannon", 9, 10, 60, False, True)])
+def test_window_1_construction_with_device_side_select_equals_the_serial_insertion(native, oracle, tmp_path, dist, d, m, efc, extend, keep):
+    """GPU-assisted construction, one point per window, select_neighbours ON THE DEVICE (hnsw_build_select_kernel; on the host
+    only when extend_candidates asks for the lists of the graph under construction): the dump must be the oracle's serially
+    built graph byte for byte -- every search_layer AND every select_neighbours (src/hnsw.rs:1299-1421, keep_pruned included;
+    dist(e, selected) with e as the first argument, which matters for the asymmetric Jeffreys / Jensen-Shannon sums)
+    took the reference's decisions."""
+    from conftest import normalized, probability, uniform
+    n = 1200
+    X = (probability(n, d, 77) if dist in ("DistJeffreys", "DistJensenShannon") else normalized(n, d, 77) if dist == "DistDot" else uniform(n, d, 77))
+    o = oracle.OracleHnsw(m, n, 16, efc, dist)
+    o.set_extend_candidates(extend)
+    o.set_keeping_pruned(keep)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "orc")
+    h = native.Hnsw(m, n, 16, efc, dist)
+    h.set_extend_candidates(extend)
+    h.set_keeping_pruned(keep)
+    h.set_build_options(nthreads=1, gpu_device=0, gpu_window=1)
+    h.parallel_insert(X)
+    h.file_dump(tmp_path, "gpu")
+    for ext in (".hnsw.graph", ".hnsw.data"):
+        assert open(tmp_path / ("orc" + ext), "rb").read() == open(tmp_path / ("gpu" + ext), "rb").read()
