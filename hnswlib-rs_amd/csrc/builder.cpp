@@ -1,6 +1,7 @@
 // builder.cpp -- see builder.hpp.  Compile with -ffp-contract=off: in reference-order mode the
 // stored edge distances must equal the crate's scalar arithmetic bit for bit.
 #include "builder.hpp"
+#include "worker_pool.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -556,18 +557,14 @@ int GraphBuilder::insert_batch(const float* data, uint64_t n, uint64_t d, const 
         return OK;
     }
     std::atomic<uint64_t> next{start};
-    auto worker = [&]() {
+    WorkerPool::instance().run((unsigned)nthreads, (unsigned)nthreads, [&](unsigned) {
         Tls t;
         for (;;) {
             uint64_t i = next.fetch_add(1);
             if (i >= n_) break;
             insert_one((uint32_t)i, t);
         }
-    };
-    std::vector<std::thread> th;
-    for (int k = 1; k < nthreads; ++k) th.emplace_back(worker);
-    worker();
-    for (auto& x : th) x.join();
+    });
     return OK;
 }
 
@@ -672,19 +669,15 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         warning_ = "GPU-assisted construction fell back to the host builder for " + std::to_string(n_ - start) + " points: " + why;
         err.clear();
         std::atomic<uint64_t> next{start};
-        auto worker = [&]() {
+        const unsigned nt = n_ - start < 64 ? 1u : (unsigned)nthreads;
+        WorkerPool::instance().run(nt, nt, [&](unsigned) {
             Tls t;
             for (;;) {
                 const uint64_t i = next.fetch_add(1);
                 if (i >= n_) break;
                 insert_one((uint32_t)i, t);
             }
-        };
-        std::vector<std::thread> th;
-        const int nt = n_ - start < 64 ? 1 : nthreads;
-        for (int k = 1; k < nt; ++k) th.emplace_back(worker);
-        worker();
-        for (auto& x : th) x.join();
+        });
         return OK;
     };
     // the device gets every vector and level, and the lists as they are now
@@ -697,22 +690,21 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
                    max_window, err);
     if (rc != OK) return finish_on_host(err);
     const uint32_t rw = dev.rec_words();
-    std::vector<uint32_t> records;
-    auto pack = [&](const std::vector<uint32_t>& dirty) {
-        records.clear();
-        records.reserve(dirty.size() * rw);
-        for (uint32_t key : dirty) {
-            const uint32_t id = key >> 4, l = key & 15u;
-            const size_t base = records.size();
-            records.resize(base + rw, NO_POINT);
-            records[base] = id;
-            records[base + 1] = l;
+    // one record = {node, layer, the list's ids, NO_POINT padding}, written whole (no separate fill pass) into the backend's
+    // pinned buffer
+    auto pack_record = [&](uint32_t* rec, uint32_t key) {
+        const uint32_t id = key >> 4, l = key & 15u;
+        rec[0] = id;
+        rec[1] = l;
+        size_t j = 0;
+        {
             Node& nd = node(id);
             SpinGuard g(nd.lock);
             const std::vector<Edge>* lst = nd.list_if(l);
             if (lst)
-                for (size_t j = 0; j < lst->size() && j + 2 < rw; ++j) records[base + 2 + j] = (*lst)[j].id;
+                for (; j < lst->size() && j + 2 < rw; ++j) rec[2 + j] = (*lst)[j].id;
         }
+        for (; j + 2 < rw; ++j) rec[2 + j] = NO_POINT;
     };
     {   // initial snapshot: every list of the points inserted so far
         std::vector<uint32_t> dirty;
@@ -721,8 +713,10 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
                 const std::vector<Edge>* lst = node((uint32_t)i).list_if(l);
                 if (lst && !lst->empty()) dirty.push_back(((uint32_t)i << 4) | l);
             }
-        pack(dirty);
-        rc = dev.patch(records, err);
+        uint32_t* rec = dev.patch_buffer(dirty.size(), err);
+        if (!dirty.empty() && !rec) return finish_on_host(err);
+        for (size_t k = 0; k < dirty.size(); ++k) pack_record(rec + k * rw, dirty[k]);
+        rc = dev.patch(dirty.size(), err);
         if (rc != OK) return finish_on_host(err);
     }
     WindowSearchResults res;
@@ -753,7 +747,9 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         const double w1 = now();
         for (auto& v : dirty_t) v.clear();
         std::atomic<uint32_t> next{0};
-        auto worker = [&](int tid) {
+        const unsigned nt = (unsigned)std::min<uint64_t>((uint64_t)nthreads, std::max<uint32_t>(1, count / 8));
+        WorkerPool& pool = WorkerPool::instance();
+        pool.run(nt, nt, [&](unsigned tid) {
             Tls t;
             t.timing = timing;
             for (;;) {
@@ -761,55 +757,35 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
                 if (wi >= count) break;
                 apply_window_point((uint32_t)start + wi, wi, frozen_entry, frozen_level, layer_mask, res, p_.ef_construction, t, dirty_t[(size_t)tid]);
             }
+            // the lists this thread changed: sorted and de-duplicated here, packed below (a list two threads touched is
+            // sent twice, with the same content)
+            auto& v = dirty_t[(size_t)tid];
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
             if (timing) {
                 std::lock_guard<std::mutex> g(entry_mutex_);
                 t_select_sum += t.t_select;
                 t_reverse_sum += t.t_reverse;
             }
-        };
-        const int nt = (int)std::min<uint64_t>((uint64_t)nthreads, std::max<uint32_t>(1, count / 8));
-        std::vector<std::thread> th;
-        for (int k = 1; k < nt; ++k) th.emplace_back(worker, k);
-        worker(0);
-        for (auto& x : th) x.join();
+        });
         const double w2 = now();
-        // the lists this window changed, packed for the device by the threads that changed them: every thread sorts
-        // and de-duplicates its own keys and packs them into its slice (a list two threads touched is sent twice, with
-        // the same content)
+        uint64_t n_records = 0;
         {
             std::vector<size_t> offs((size_t)nt + 1, 0);
-            auto dedup = [&](int tid) {
-                auto& v = dirty_t[(size_t)tid];
-                std::sort(v.begin(), v.end());
-                v.erase(std::unique(v.begin(), v.end()), v.end());
-            };
-            std::vector<std::thread> th2;
-            for (int k = 1; k < nt; ++k) th2.emplace_back(dedup, k);
-            dedup(0);
-            for (auto& x : th2) x.join();
-            for (int k = 0; k < nt; ++k) offs[(size_t)k + 1] = offs[(size_t)k] + dirty_t[(size_t)k].size();
-            records.assign(offs[(size_t)nt] * rw, NO_POINT);
-            auto pack_slice = [&](int tid) {
-                size_t base = offs[(size_t)tid] * rw;
+            for (unsigned k = 0; k < nt; ++k) offs[(size_t)k + 1] = offs[(size_t)k] + dirty_t[(size_t)k].size();
+            n_records = offs[(size_t)nt];
+            uint32_t* rec = dev.patch_buffer(n_records, err);
+            if (n_records != 0 && !rec) { start += count; if (start < n_) return finish_on_host(err); warning_ = err; err.clear(); return OK; }
+            pool.run(nt, nt, [&](unsigned tid) {
+                uint32_t* out = rec + offs[(size_t)tid] * rw;
                 for (uint32_t key : dirty_t[(size_t)tid]) {
-                    const uint32_t id = key >> 4, l = key & 15u;
-                    records[base] = id;
-                    records[base + 1] = l;
-                    Node& nd = node(id);
-                    SpinGuard g(nd.lock);
-                    const std::vector<Edge>* lst = nd.list_if(l);
-                    if (lst)
-                        for (size_t j = 0; j < lst->size() && j + 2 < rw; ++j) records[base + 2 + j] = (*lst)[j].id;
-                    base += rw;
+                    pack_record(out, key);
+                    out += rw;
                 }
-            };
-            th2.clear();
-            for (int k = 1; k < nt; ++k) th2.emplace_back(pack_slice, k);
-            pack_slice(0);
-            for (auto& x : th2) x.join();
+            });
         }
         start += count;  // this window is linked on the host whatever happens to the snapshot
-        rc = dev.patch(records, err);
+        rc = dev.patch(n_records, err);
         if (rc != OK) { if (start < n_) return finish_on_host(err); warning_ = err; err.clear(); return OK; }
         t_search += w1 - w0;
         t_apply += w2 - w1;

@@ -70,9 +70,12 @@ public:
     virtual int begin(const float* const* chunks, uint64_t chunk_rows, uint64_t n, uint64_t d, const uint8_t* levels, int dist,
                       uint64_t max_nb_connection, uint64_t ef_construction, unsigned top_layer, uint64_t max_window,
                       std::string& err) = 0;
-    // replace lists of the snapshot: records of rec_words() u32 = {node, layer, ids..., NO_POINT padding}
+    // replace lists of the snapshot: records of rec_words() u32 = {node, layer, ids..., NO_POINT padding}.  The records are
+    // packed straight into patch_buffer(n_records) -- pinned host memory of the backend, valid until the next call -- and
+    // patch(n_records) sends them
     virtual uint32_t rec_words() const = 0;
-    virtual int patch(const std::vector<uint32_t>& records, std::string& err) = 0;
+    virtual uint32_t* patch_buffer(uint64_t n_records, std::string& err) = 0;
+    virtual int patch(uint64_t n_records, std::string& err) = 0;
     // layer_mask: bit l set when some inserted point has level exactly l (search_layer returns nothing on other layers)
     virtual int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask,
                               const WindowSelect& select, WindowSearchResults& out, std::string& err) = 0;

@@ -32,6 +32,7 @@
 #include "hnswio.hpp"
 #include "search_device.hpp"
 #include "search_kernels.hpp"
+#include "worker_pool.hpp"
 
 namespace hnswgpu {
 
@@ -664,28 +665,18 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     return OK;
 }
 
-// a few host threads for the staging copies of one call (a 10 000 x 128 batch is 5 MB in and 1.7 MB out: one core needs
+// the staging copies of one call on a few pool threads (a 10 000 x 128 batch is 5 MB in and 1.7 MB out: one core needs
 // ~0.5 ms for it, a third of the search itself); small jobs stay on the calling thread
 template <class F>
 static void parallel_chunks(uint64_t n, uint64_t bytes_per_item, F&& fn) {
     const uint64_t total = n * bytes_per_item;
-    unsigned nt = total < (512u << 10) ? 1u : (unsigned)std::min<uint64_t>(4, std::max<uint64_t>(1, total / (256u << 10)));
-    nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned nt = total < (256u << 10) ? 1u : (unsigned)std::min<uint64_t>(8, std::max<uint64_t>(1, total / (128u << 10)));
     if (nt <= 1 || n < nt) { fn((uint64_t)0, n); return; }
-    std::vector<std::thread> th;
     const uint64_t per = (n + nt - 1) / nt;
-    try {
-        for (unsigned t = 1; t < nt; ++t) {
-            const uint64_t b = std::min<uint64_t>(n, t * per), e = std::min<uint64_t>(n, (t + 1) * per);
-            if (b < e) th.emplace_back([&fn, b, e]() { fn(b, e); });
-        }
-    } catch (...) {  // thread creation failed: finish what was started, do the rest here
-        for (auto& x : th) x.join();
-        fn((uint64_t)0, n);
-        return;
-    }
-    fn((uint64_t)0, std::min<uint64_t>(n, per));
-    for (auto& x : th) x.join();
+    WorkerPool::instance().run(nt, nt, [&](unsigned t) {
+        const uint64_t b = std::min<uint64_t>(n, (uint64_t)t * per), e = std::min<uint64_t>(n, ((uint64_t)t + 1) * per);
+        if (b < e) fn(b, e);
+    });
 }
 
 int DeviceIndex::search_host_staged(const float* queries, const float* const* rows, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
@@ -804,6 +795,7 @@ public:
         DeviceGuard on_device(device_);
         for (DevBuf* b : {&vec_, &level_, &nrm2_, &slot0_, &out_ids_, &out_d_, &out_n_, &hit_ids_, &hit_d_, &bitmap_, &upd_, &slot_nb_, &sel_ids_, &sel_d_, &sel_n_}) b->free();
         for (auto& b : lists_) b.free();
+        upd_host_.free();
         if (d_ctrl_) (void)hipFree(d_ctrl_);
     }
     int check(uint64_t ef_construction, std::string& err) override {
@@ -858,17 +850,25 @@ public:
         return OK;
     }
     uint32_t rec_words() const override { return 2u + max_stride_; }
-    int patch(const std::vector<uint32_t>& records, std::string& err) override {
-        if (records.empty()) return OK;
+    uint32_t* patch_buffer(uint64_t n_records, std::string& err) override {
+        DeviceGuard on_device(device_);
+        const hipError_t e = upd_host_.ensure(std::max<uint64_t>(1, n_records) * rec_words() * sizeof(uint32_t));
+        if (e != hipSuccess) { err = std::string("pinned buffer for the list updates: ") + hipGetErrorString(e); return nullptr; }
+        return static_cast<uint32_t*>(upd_host_.p);
+    }
+    int patch(uint64_t n_records, std::string& err) override {
+        if (n_records == 0) return OK;
         DeviceGuard on_device(device_);
         HIP_TRY(on_device.status());
         const uint32_t rw = rec_words();
-        const uint32_t n_upd = (uint32_t)(records.size() / rw);
-        for (uint32_t u = 0; u < n_upd; ++u)
-            if (records[(size_t)u * rw + 1] > top_layer_ || records[(size_t)u * rw] >= n_) { err = "internal error: list update outside the snapshot"; return ERR_ARG; }
-        HIP_TRY(upd_.ensure(records.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(upd_.p, records.data(), records.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(launch_scatter_lists(nullptr, upd_.as<uint32_t>(), n_upd, rw, bl_));
+        const uint32_t* records = static_cast<const uint32_t*>(upd_host_.p);
+        if (!records || upd_host_.cap < n_records * rw * sizeof(uint32_t)) { err = "internal error: list updates were not packed into patch_buffer"; return ERR_ARG; }
+        if (n_records > 0xFFFFFFFFull) { err = "too many list updates"; return ERR_ARG; }
+        for (uint64_t u = 0; u < n_records; ++u)
+            if (records[u * rw + 1] > top_layer_ || records[u * rw] >= n_) { err = "internal error: list update outside the snapshot"; return ERR_ARG; }
+        HIP_TRY(upd_.ensure(n_records * rw * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(upd_.p, records, n_records * rw * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));  // pinned: a DMA at link speed
+        HIP_TRY(launch_scatter_lists(nullptr, upd_.as<uint32_t>(), (uint32_t)n_records, rw, bl_));
         HIP_TRY(hipDeviceSynchronize());
         return OK;
     }
@@ -1015,6 +1015,7 @@ private:
     unsigned top_layer_ = 0;
     DevBuf vec_, level_, nrm2_, slot0_, out_ids_, out_d_, out_n_, hit_ids_, hit_d_, bitmap_, upd_, slot_nb_, sel_ids_, sel_d_, sel_n_;
     std::vector<uint16_t> slot_nb_h_;
+    PinnedBuf upd_host_;
     DevBuf lists_[NB_LAYER_MAX];
     BuildLists bl_{};
     void* d_ctrl_ = nullptr;
