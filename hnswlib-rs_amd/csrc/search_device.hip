@@ -164,7 +164,7 @@ struct PinnedBuf {
 };
 
 struct DeviceIndex::Workspace {
-    DevBuf qpad, tie, predist, order, retry[2], stats, bitmap, heaps, cand, oplog, allow, allowed_ids, hostio[5];
+    DevBuf qpad, tie, predist, order, retry[2], stats, bitmap, heaps, cand, oplog, allow, allowed_ids, hostio[2];
     PinnedBuf pin_in, pin_out;
     void* d_ctrl = nullptr;   // work counter + counters
     void* h_ctrl = nullptr;   // pinned host copy (read back once per launch)
@@ -182,7 +182,7 @@ struct DeviceIndex::Workspace {
     }
     ~Workspace() {
         for (DevBuf* b : {&qpad, &tie, &predist, &order, &retry[0], &retry[1], &stats, &bitmap, &heaps, &cand, &oplog, &allow,
-                          &allowed_ids, &hostio[0], &hostio[1], &hostio[2], &hostio[3], &hostio[4]})
+                          &allowed_ids, &hostio[0], &hostio[1]})
             b->free();
         pin_in.free();
         pin_out.free();
@@ -695,50 +695,55 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     if (!lease.get()) return ERR_DEVICE;
     Workspace& w = *lease.get();
     hipStream_t stream = w.own_stream;
-    // device side: queries | ids | dists | rank | layer | counts
-    HIP_TRY(w.hostio[0].ensure(nq * d * sizeof(float)));
-    HIP_TRY(w.hostio[1].ensure(nq * k * sizeof(uint64_t)));
-    HIP_TRY(w.hostio[2].ensure(nq * k * sizeof(float)));
-    HIP_TRY(w.hostio[3].ensure(nq * k * (sizeof(int32_t) + 1)));
-    HIP_TRY(w.hostio[4].ensure(nq * sizeof(uint32_t)));
-    HIP_TRY(w.stats.ensure(nq * 8 * sizeof(uint32_t)));
-    // pinned host side: the same arrays (+ the per-query status words of a filtered search)
+    // one arena on each side for the answers -- ids | dists | rank | layer | counts -- so that they come back in ONE copy
     const uint64_t q_bytes = nq * d * sizeof(float);
     const uint64_t o_ids = 0, o_dists = o_ids + nq * k * sizeof(uint64_t), o_rank = o_dists + nq * k * sizeof(float),
                    o_layer = o_rank + nq * k * sizeof(int32_t), o_cnt = (o_layer + nq * k + 7) & ~7ull,
-                   o_stat = o_cnt + nq * sizeof(uint32_t), o_end = o_stat + (want_status ? nq * 8 * sizeof(uint32_t) + nq : 0);
+                   o_ans_end = o_cnt + nq * sizeof(uint32_t), o_stat = (o_ans_end + 7) & ~7ull,
+                   o_end = o_stat + (want_status ? nq * 8 * sizeof(uint32_t) + nq : 0);
+    HIP_TRY(w.hostio[0].ensure(q_bytes));
+    HIP_TRY(w.hostio[1].ensure(o_ans_end));
+    HIP_TRY(w.stats.ensure(nq * 8 * sizeof(uint32_t)));
     HIP_TRY(w.pin_in.ensure(q_bytes));
     HIP_TRY(w.pin_out.ensure(o_end));
     float* hq = static_cast<float*>(w.pin_in.p);
     unsigned char* ho = static_cast<unsigned char*>(w.pin_out.p);
     float* dq = w.hostio[0].as<float>();
-    uint64_t* dids = w.hostio[1].as<uint64_t>();
-    float* ddist = w.hostio[2].as<float>();
-    int32_t* drank = w.hostio[3].as<int32_t>();
-    uint8_t* dlayer = reinterpret_cast<uint8_t*>(drank + nq * k);
-    uint32_t* dcnt = w.hostio[4].as<uint32_t>();
+    unsigned char* dout = w.hostio[1].as<unsigned char>();
+    uint64_t* dids = reinterpret_cast<uint64_t*>(dout + o_ids);
+    float* ddist = reinterpret_cast<float*>(dout + o_dists);
+    int32_t* drank = reinterpret_cast<int32_t*>(dout + o_rank);
+    uint8_t* dlayer = dout + o_layer;
+    uint32_t* dcnt = reinterpret_cast<uint32_t*>(dout + o_cnt);
     const uint64_t* dallowed = nullptr;
     if (filtered) {
         HIP_TRY(w.allowed_ids.ensure(std::max<uint64_t>(1, n_allowed) * sizeof(uint64_t)));
         if (n_allowed) HIP_TRY(hipMemcpyAsync(w.allowed_ids.p, allowed, n_allowed * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         dallowed = w.allowed_ids.as<uint64_t>();
     }
-    // gather (contiguous matrix or row pointers) into pinned memory, then one asynchronous copy
-    if (queries) {
-        parallel_chunks(nq, d * sizeof(float), [&](uint64_t b, uint64_t e) { std::memcpy(hq + b * d, queries + b * d, (e - b) * d * sizeof(float)); });
-    } else {
-        parallel_chunks(nq, d * sizeof(float), [&](uint64_t b, uint64_t e) {
-            for (uint64_t i = b; i < e; ++i) std::memcpy(hq + i * d, rows[i], d * sizeof(float));
-        });
+    // gather (contiguous matrix or row pointers) into pinned memory in a few pieces, every piece followed at once by its
+    // asynchronous copy: the DMA of one piece runs under the gathering of the next
+    {
+        const uint64_t row_bytes = d * sizeof(float);
+        const uint64_t piece = std::max<uint64_t>(1, std::min<uint64_t>(nq, (1u << 20) / std::max<uint64_t>(1, row_bytes) + 1));
+        for (uint64_t p0 = 0; p0 < nq; p0 += piece) {
+            const uint64_t p1 = std::min(nq, p0 + piece);
+            if (queries) {
+                parallel_chunks(p1 - p0, row_bytes, [&](uint64_t b, uint64_t e) {
+                    std::memcpy(hq + (p0 + b) * d, queries + (p0 + b) * d, (e - b) * row_bytes);
+                });
+            } else {
+                parallel_chunks(p1 - p0, row_bytes, [&](uint64_t b, uint64_t e) {
+                    for (uint64_t i = p0 + b; i < p0 + e; ++i) std::memcpy(hq + i * d, rows[i], row_bytes);
+                });
+            }
+            HIP_TRY(hipMemcpyAsync(dq + p0 * d, hq + p0 * d, (p1 - p0) * row_bytes, hipMemcpyHostToDevice, stream));
+        }
     }
-    HIP_TRY(hipMemcpyAsync(dq, hq, q_bytes, hipMemcpyHostToDevice, stream));
     int rc = search_device(dq, nq, d, k, ef, dids, ddist, dlayer, drank, dcnt, w.stats.as<uint32_t>(), stream, dallowed,
                            filtered ? n_allowed : 0, info, err);
     if (rc != OK) return rc;
-    HIP_TRY(hipMemcpyAsync(ho + o_ids, dids, nq * k * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(ho + o_dists, ddist, nq * k * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(ho + o_rank, drank, nq * k * (sizeof(int32_t) + 1), hipMemcpyDeviceToHost, stream));  // rank, then layer
-    HIP_TRY(hipMemcpyAsync(ho + o_cnt, dcnt, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(ho, dout, o_ans_end, hipMemcpyDeviceToHost, stream));
     if (want_status) HIP_TRY(hipMemcpyAsync(ho + o_stat, w.stats.p, nq * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(wait_stream(stream));
     HostAnswers a{};
