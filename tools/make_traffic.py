@@ -9,9 +9,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = {}
-for cfg in ("sift1m", "glove25", "mnist784"):
+for cfg in ("sift1m", "glove25", "glove25_dot", "mnist784"):
     sp = os.path.join(ROOT, "profiles", f"{tag}_{cfg}_rocprofv3_summary.txt")
     bp = os.path.join(ROOT, "profiles", f"{tag}_bench_{cfg}.json")
     if not (os.path.exists(sp) and os.path.exists(bp)):
