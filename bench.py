@@ -213,8 +213,16 @@ def probe_rccl_on_one_device(n_ranks, seconds=90):
             return False, f"RCCL did not complete an all_reduce of {n_ranks} ranks sharing HIP device 0 within {seconds} s (it hangs instead of refusing)"
         if p.returncode == 0:
             return True, None
-        lines = [l.strip() for l in (out or "").splitlines() if "Duplicate GPU" in l or "NCCL" in l or "ncclInvalid" in l or "invalid usage" in l]
-        lines = lines or [l.strip() for l in (out or "").splitlines() if "Error" in l and "traceback" not in l]
+        text = [l.strip() for l in (out or "").splitlines() if l.strip() and "amdgpu.ids" not in l]
+        for l in text[-25:]:
+            log("rccl probe | " + l[:300])
+        keys = ("Duplicate GPU", "ncclInvalidUsage", "invalid usage", "NCCL error", "ncclSystemError", "ncclUnhandled", "DistBackendError",
+                "RuntimeError", "HIP error", "Error")
+        lines = []
+        for key in keys:  # the most telling line there is, never one of torch's shutdown warnings
+            lines = [l for l in text if key in l and "Warning" not in l and "WARNING" not in l and "traceback" not in l]
+            if lines:
+                break
         return False, ("RCCL refused %d ranks on one device: %s" % (n_ranks, (lines[-1] if lines else "exit code %d" % p.returncode)[:240]))
 
 

@@ -560,12 +560,22 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             a.merge_entries = (uint32_t)slots * 64u + 64u;
             lds += (size_t)a.merge_entries * sizeof(hent_t);
         }
-        if (strict_kernel) {  // top levels of the (lazy) literal candidate heap, for the few pops that need it
+        int per_cu = 0;
+        if (strict_kernel) {
+            // top levels of the (lazy) literal candidate heap, for the few pops that need it: 512 entries when that costs no
+            // resident wave (the strict kernel sits at 4 waves per SIMD by its registers, which leaves ~10 KB of LDS per
+            // wave), else 256 -- a replay touches the heap ~800 times per query, every level out of LDS is an L2 round trip
             a.cand_lds = 256;
-            if (const char* e = std::getenv("HNSWGPU_CAND_LDS")) a.cand_lds = (uint32_t)std::max(0, std::min(4096, std::atoi(e)));  // tuning hook
+            if (const char* e = std::getenv("HNSWGPU_CAND_LDS")) {
+                a.cand_lds = (uint32_t)std::max(0, std::min(4096, std::atoi(e)));  // tuning hook
+            } else {
+                int occ256 = 0, occ512 = 0;
+                HIP_TRY(ks.occupancy(slots, table, true, lds + 256 * sizeof(hent_t), &occ256));
+                HIP_TRY(ks.occupancy(slots, table, true, lds + 512 * sizeof(hent_t), &occ512));
+                if (occ512 >= occ256) a.cand_lds = 512;
+            }
             lds += (size_t)a.cand_lds * sizeof(hent_t);
         }
-        int per_cu = 0;
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));
         if (per_cu < 1) per_cu = 1;
         if (const char* e = std::getenv("HNSWGPU_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // tuning hook
@@ -721,24 +731,18 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         if (n_allowed) HIP_TRY(hipMemcpyAsync(w.allowed_ids.p, allowed, n_allowed * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         dallowed = w.allowed_ids.as<uint64_t>();
     }
-    // gather (contiguous matrix or row pointers) into pinned memory in a few pieces, every piece followed at once by its
-    // asynchronous copy: the DMA of one piece runs under the gathering of the next
+    // gather (contiguous matrix or row pointers) into pinned memory on a few pool threads, then one asynchronous copy
+    // (gathering in pieces with a copy behind each was measured: the extra dispatches cost more than the overlap gives)
     {
         const uint64_t row_bytes = d * sizeof(float);
-        const uint64_t piece = std::max<uint64_t>(1, std::min<uint64_t>(nq, (1u << 20) / std::max<uint64_t>(1, row_bytes) + 1));
-        for (uint64_t p0 = 0; p0 < nq; p0 += piece) {
-            const uint64_t p1 = std::min(nq, p0 + piece);
-            if (queries) {
-                parallel_chunks(p1 - p0, row_bytes, [&](uint64_t b, uint64_t e) {
-                    std::memcpy(hq + (p0 + b) * d, queries + (p0 + b) * d, (e - b) * row_bytes);
-                });
-            } else {
-                parallel_chunks(p1 - p0, row_bytes, [&](uint64_t b, uint64_t e) {
-                    for (uint64_t i = p0 + b; i < p0 + e; ++i) std::memcpy(hq + i * d, rows[i], row_bytes);
-                });
-            }
-            HIP_TRY(hipMemcpyAsync(dq + p0 * d, hq + p0 * d, (p1 - p0) * row_bytes, hipMemcpyHostToDevice, stream));
+        if (queries) {
+            parallel_chunks(nq, row_bytes, [&](uint64_t b, uint64_t e) { std::memcpy(hq + b * d, queries + b * d, (e - b) * row_bytes); });
+        } else {
+            parallel_chunks(nq, row_bytes, [&](uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e; ++i) std::memcpy(hq + i * d, rows[i], row_bytes);
+            });
         }
+        HIP_TRY(hipMemcpyAsync(dq, hq, q_bytes, hipMemcpyHostToDevice, stream));
     }
     int rc = search_device(dq, nq, d, k, ef, dids, ddist, dlayer, drank, dcnt, w.stats.as<uint32_t>(), stream, dallowed,
                            filtered ? n_allowed : 0, info, err);
