@@ -174,22 +174,98 @@ struct EdgeGreater {
 
 }  // namespace
 
+// A neighbour list that lock-free readers may copy while a writer (node lock held, sequence counter odd) changes it: the
+// buffer is published ONCE through an atomic pointer and keeps its place until the builder dies -- a reader never follows a
+// pointer to freed memory, and every word it can see is read and written atomically (its copy is validated by the sequence
+// counter).  A list that outgrows its buffer (only a foreign dump with over-long lists can do that) moves to a larger one; the
+// old buffer is retired, not freed.  The writer-side interface is the slice of std::vector the builder uses.
+class EdgeList {
+public:
+    EdgeList() = default;
+    EdgeList(const EdgeList&) = delete;
+    EdgeList& operator=(const EdgeList&) = delete;
+    ~EdgeList() {
+        delete[] data_.load(std::memory_order_relaxed);
+        for (Edge* p : retired_) delete[] p;
+    }
+    // ---- readers (no lock)
+    void snapshot(const Edge*& p, uint32_t& n) const {
+        n = size_.load(std::memory_order_acquire);
+        p = data_.load(std::memory_order_acquire);
+    }
+    // ---- writers (node lock held) and single-threaded phases
+    size_t size() const { return size_.load(std::memory_order_relaxed); }
+    bool empty() const { return size() == 0; }
+    const Edge* begin() const { return data_.load(std::memory_order_relaxed); }
+    const Edge* end() const { return begin() + size(); }
+    const Edge& operator[](size_t i) const { return begin()[i]; }
+    void reserve(size_t cap) {
+        if (cap <= cap_) return;
+        Edge* fresh = new Edge[cap];
+        Edge* old = data_.load(std::memory_order_relaxed);
+        const size_t n = size();
+        for (size_t i = 0; i < n; ++i) put(fresh, i, old[i]);
+        data_.store(fresh, std::memory_order_release);
+        cap_ = (uint32_t)cap;
+        if (old) retired_.push_back(old);
+    }
+    void push_back(const Edge& e) {
+        const size_t n = size();
+        if (n + 1 > cap_) reserve(n + 2);
+        put(data_.load(std::memory_order_relaxed), n, e);
+        size_.store((uint32_t)(n + 1), std::memory_order_release);
+    }
+    void pop_back() { size_.store((uint32_t)(size() - 1), std::memory_order_release); }
+    void insert_at(size_t pos, const Edge& e) {  // keeps the order of the others
+        const size_t n = size();
+        if (n + 1 > cap_) reserve(n + 2);
+        Edge* d = data_.load(std::memory_order_relaxed);
+        for (size_t i = n; i > pos; --i) put(d, i, d[i - 1]);
+        put(d, pos, e);
+        size_.store((uint32_t)(n + 1), std::memory_order_release);
+    }
+    void assign(const std::vector<Edge>& v) {
+        if (v.size() > cap_) reserve(v.size() + 2);
+        Edge* d = data_.load(std::memory_order_relaxed);
+        for (size_t i = 0; i < v.size(); ++i) put(d, i, v[i]);
+        size_.store((uint32_t)v.size(), std::memory_order_release);
+    }
+
+private:
+    static void put(Edge* d, size_t i, const Edge& e) {
+        static_assert(sizeof(Edge) == 8, "an edge is one 64-bit word");
+        uint64_t w;
+        std::memcpy(&w, &e, 8);
+        __atomic_store_n(reinterpret_cast<uint64_t*>(d + i), w, __ATOMIC_RELAXED);
+    }
+    std::atomic<Edge*> data_{nullptr};
+    std::atomic<uint32_t> size_{0};
+    uint32_t cap_ = 0;
+    std::vector<Edge*> retired_;
+};
+
 struct GraphBuilder::Node {
     std::atomic<uint8_t> lock{0};      // writers (one at a time)
     std::atomic<uint32_t> seq{0};      // odd while a writer is inside: readers copy a list without any lock and retry
     uint8_t level = 0;
     int32_t rank = 0;
     uint64_t origin = 0;
-    std::vector<Edge> l0;                      // neighbours[0]
-    std::unique_ptr<std::vector<Edge>[]> up;   // neighbours[1..15], allocated on first use
-    std::vector<Edge>& list(unsigned l) {
+    EdgeList l0;                           // neighbours[0]
+    std::atomic<EdgeList*> up{nullptr};    // neighbours[1..15], allocated on first use (published once, freed with the node)
+    ~Node() { delete[] up.load(std::memory_order_relaxed); }
+    EdgeList& list(unsigned l) {
         if (l == 0) return l0;
-        if (!up) up.reset(new std::vector<Edge>[NB_LAYER_MAX - 1]);
-        return up[l - 1];
+        EdgeList* u = up.load(std::memory_order_acquire);
+        if (!u) {
+            u = new EdgeList[NB_LAYER_MAX - 1];
+            up.store(u, std::memory_order_release);
+        }
+        return u[l - 1];
     }
-    const std::vector<Edge>* list_if(unsigned l) const {
+    const EdgeList* list_if(unsigned l) const {
         if (l == 0) return &l0;
-        return up ? &up[l - 1] : nullptr;
+        const EdgeList* u = up.load(std::memory_order_acquire);
+        return u ? &u[l - 1] : nullptr;
     }
 };
 
@@ -262,13 +338,12 @@ GraphBuilder::GraphBuilder(const FlatIndex& f, bool fast_arithmetic) {
         for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
             const uint64_t b = f.nbr_ptr[i * NB_LAYER_MAX + l], e = f.nbr_ptr[i * NB_LAYER_MAX + l + 1];
             if (e == b) continue;
-            std::vector<Edge>& lst = nd.list(l);
-            // reserved here, before any worker thread exists, to the most the list can reach (a longer list of a foreign dump
-            // included): readers copy lists without a lock and must never meet a reallocation
+            EdgeList& lst = nd.list(l);
+            // sized here, before any worker thread exists, for the most the list can reach (a longer list of a foreign dump
+            // included)
             const size_t cap = (l == 0 ? 2 * (size_t)p_.max_nb_connection : (size_t)p_.max_nb_connection) + 2;
             lst.reserve(std::max<size_t>(cap, (size_t)(e - b) + 2));
-            lst.resize(e - b);
-            for (uint64_t j = b; j < e; ++j) lst[j - b] = Edge{f.nbr_flat[j], f.nbr_dist[j]};
+            for (uint64_t j = b; j < e; ++j) lst.push_back(Edge{f.nbr_flat[j], f.nbr_dist[j]});
         }
     }
     if (f.entry_flat != NO_POINT) {
@@ -322,11 +397,11 @@ void GraphBuilder::read_list(uint32_t id, unsigned layer, std::vector<Edge>& out
     for (;;) {
         const uint32_t s1 = nd.seq.load(std::memory_order_acquire);
         if (s1 & 1u) { cpu_relax(); continue; }
-        const std::vector<Edge>* l = nd.list_if(layer);
-        size_t n = 0;
+        const EdgeList* l = nd.list_if(layer);
+        uint32_t n = 0;
         const Edge* p = nullptr;
-        if (l) { n = l->size(); p = l->data(); }
-        if (n > 1024 || (n != 0 && p == nullptr)) continue;  // torn begin / end pointers: a writer is inside
+        if (l) l->snapshot(p, n);
+        if (n != 0 && p == nullptr) continue;  // (length and buffer of two different moments: a writer is inside)
         out.resize(n);
         for (size_t i = 0; i < n; ++i) {
             const uint64_t w = __atomic_load_n(reinterpret_cast<const uint64_t*>(p + i), __ATOMIC_RELAXED);
@@ -338,10 +413,10 @@ void GraphBuilder::read_list(uint32_t id, unsigned layer, std::vector<Edge>& out
 }
 
 // a node's list for writing (under a WriteGuard): its buffer is reserved once, to the most it can ever hold
-std::vector<Edge>& GraphBuilder::wlist(Node& nd, unsigned layer) const {
-    std::vector<Edge>& v = nd.list(layer);
+EdgeList& GraphBuilder::wlist(Node& nd, unsigned layer) const {
+    EdgeList& v = nd.list(layer);
     const size_t cap = (layer == 0 ? 2 * (size_t)p_.max_nb_connection : (size_t)p_.max_nb_connection) + 2;
-    if (v.capacity() < cap) v.reserve(std::max(cap, v.size() + 2));
+    v.reserve(std::max(cap, v.size() + 2));  // (no-op once the buffer exists with that capacity)
     return v;
 }
 
@@ -437,7 +512,7 @@ void GraphBuilder::reverse_update(uint32_t id, Tls& t) {
             if (q.id == id) continue;
             Node& qn = node(q.id);
             WriteGuard g(qn);
-            std::vector<Edge>& lst = wlist(qn, level);  // list at the NEW point's level (:1257)
+            EdgeList& lst = wlist(qn, level);  // list at the NEW point's level (:1257)
             bool already = false;
             for (const Edge& old : lst)
                 if (old.id == id) { already = true; break; }
@@ -446,8 +521,8 @@ void GraphBuilder::reverse_update(uint32_t id, Tls& t) {
             // push + sort_unstable + pop-if-over (:1268-1283): lists are always ascending, so this is
             // an insertion after the last element <= the new distance
             Edge ne{id, q.dist};
-            auto pos = std::upper_bound(lst.begin(), lst.end(), ne, EdgeLess());
-            lst.insert(pos, ne);
+            const Edge* pos = std::upper_bound(lst.begin(), lst.end(), ne, EdgeLess());
+            lst.insert_at((size_t)(pos - lst.begin()), ne);
             if (lst.size() > threshold) lst.pop_back();
         }
     }
@@ -478,7 +553,7 @@ void GraphBuilder::insert_one(uint32_t id, Tls& t) {
             Edge hit = t.res[0];
             {
                 WriteGuard g(np);
-                std::vector<Edge>& lst = wlist(np, (unsigned)l);
+                EdgeList& lst = wlist(np, (unsigned)l);
                 if (lst.size() < (size_t)(uint8_t)p_.max_nb_connection) lst.push_back(hit);  // :1140-1144
             }
             if (hit.dist < dist_to_entry) {
@@ -496,7 +571,7 @@ void GraphBuilder::insert_one(uint32_t id, Tls& t) {
             std::stable_sort(t.sel.begin(), t.sel.end(), EdgeLess());  // :1195
             {
                 WriteGuard g(np);
-                wlist(np, (unsigned)l) = t.sel;  // :1197
+                wlist(np, (unsigned)l).assign(t.sel);  // :1197
             }
             if (!t.sel.empty()) enter = t.sel[0].id;  // :1201-1203
         }
@@ -580,7 +655,7 @@ void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_
         const uint32_t hid = r.hit_ids[(size_t)wi * NB_LAYER_MAX + (unsigned)l];
         if (hid == NO_POINT) continue;
         WriteGuard g(np);
-        std::vector<Edge>& lst = wlist(np, (unsigned)l);
+        EdgeList& lst = wlist(np, (unsigned)l);
         if (lst.size() < (size_t)(uint8_t)p_.max_nb_connection) lst.push_back(Edge{hid, r.hit_d[(size_t)wi * NB_LAYER_MAX + (unsigned)l]});  // :1140-1144
         dirty.push_back((id << 4) | (uint32_t)l);
     }
@@ -616,7 +691,7 @@ void GraphBuilder::apply_window_point(uint32_t id, uint32_t wi, uint32_t frozen_
             std::stable_sort(t.sel.begin(), t.sel.end(), EdgeLess());  // :1195
             {
                 WriteGuard g(np);
-                wlist(np, (unsigned)l) = t.sel;  // :1197
+                wlist(np, (unsigned)l).assign(t.sel);  // :1197
             }
             dirty.push_back((id << 4) | (uint32_t)l);
         }
@@ -700,7 +775,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         {
             Node& nd = node(id);
             SpinGuard g(nd.lock);
-            const std::vector<Edge>* lst = nd.list_if(l);
+            const EdgeList* lst = nd.list_if(l);
             if (lst)
                 for (; j < lst->size() && j + 2 < rw; ++j) rec[2 + j] = (*lst)[j].id;
         }
@@ -710,7 +785,7 @@ int GraphBuilder::insert_batch_gpu(const float* data, uint64_t n, uint64_t d, co
         std::vector<uint32_t> dirty;
         for (uint64_t i = 0; i < start; ++i)
             for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
-                const std::vector<Edge>* lst = node((uint32_t)i).list_if(l);
+                const EdgeList* lst = node((uint32_t)i).list_if(l);
                 if (lst && !lst->empty()) dirty.push_back(((uint32_t)i << 4) | l);
             }
         uint32_t* rec = dev.patch_buffer(dirty.size(), err);
@@ -834,7 +909,7 @@ void GraphBuilder::finalize(FlatIndex& out) const {
     for (uint64_t f = 0; f < n_; ++f) {
         const Node& nd = node(id_of_flat[f]);
         for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
-            const std::vector<Edge>* lst = nd.list_if(l);
+            const EdgeList* lst = nd.list_if(l);
             total += lst ? lst->size() : 0;
             out.nbr_ptr[f * NB_LAYER_MAX + l + 1] = total;
         }
@@ -847,7 +922,7 @@ void GraphBuilder::finalize(FlatIndex& out) const {
         out.origin_id[f] = nd.origin;
         std::memcpy(out.vectors.data() + f * d_, vec(id), d_ * sizeof(float));
         for (unsigned l = 0; l < NB_LAYER_MAX; ++l) {
-            const std::vector<Edge>* lst = nd.list_if(l);
+            const EdgeList* lst = nd.list_if(l);
             if (!lst) continue;
             uint64_t b = out.nbr_ptr[f * NB_LAYER_MAX + l];
             for (size_t j = 0; j < lst->size(); ++j) {

@@ -81,6 +81,8 @@ public:
                               const WindowSelect& select, WindowSearchResults& out, std::string& err) = 0;
 };
 
+class EdgeList;  // a neighbour list lock-free readers may copy while it is written (builder.cpp)
+
 class GraphBuilder {
 public:
     explicit GraphBuilder(const BuildParams& p);
@@ -122,7 +124,7 @@ private:
                            unsigned layer, Tls& t, std::vector<Edge>& out);
     void reverse_update(uint32_t id, Tls& t);
     void read_list(uint32_t id, unsigned layer, std::vector<Edge>& out) const;
-    std::vector<Edge>& wlist(Node& nd, unsigned layer) const;
+    EdgeList& wlist(Node& nd, unsigned layer) const;
 
     BuildParams p_;
     uint64_t n_ = 0, d_ = 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-expansion cost of the search kernel's phases from a profiling build (make TUNE=-DHNSW_PHASE_TIMING=1) run through
-`bench.py --dump-stats`.  In such a build stats = [n_dist, n_expand, gather_cycles, dist_cycles, t_start, t_end,
+`bench.py --dump-stats`.  In such a build stats = [expansions whose id row was not prefetched, n_expand, gather_cycles, dist_cycles, t_start, t_end,
 insert_cycles, select_cycles] (cycle counts of clock64, summed over the query's expansions)."""
 import sys
 
@@ -19,4 +19,4 @@ for path in sys.argv[1:]:
         f = lambda a: np.median(a[m] / nexp[m])
         print(f"{path} [{name}, {m.sum()} queries]: per expansion: {f(dur_us):.2f} us | cycles: select+ids {f(sel):.0f}, "
               f"visited+compaction {f(gather - dist):.0f}, rows+distances {f(dist):.0f}, inserts {f(ins):.0f}, sum {f(tot):.0f}; "
-              f"clock/us ~ {np.median(tot[m] / np.maximum(dur_us[m], 1e-3)):.0f}")
+              f"clock/us ~ {np.median(tot[m] / np.maximum(dur_us[m], 1e-3)):.0f}; id-row prefetch missed in {st[m, 0].sum() / nexp[m].sum():.1%} of the expansions")
