@@ -1,0 +1,46 @@
+// Stress of csrc/worker_pool.hpp (the long-lived helper threads of the staging copies and of the construction windows):
+// every task index runs exactly once per section, sections of different sizes follow each other, a section started from
+// inside a section and sections from concurrent callers run inline instead of deadlocking.
+#include <atomic>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+#include "worker_pool.hpp"
+
+using hnswgpu::WorkerPool;
+
+int main() {
+    WorkerPool& pool = WorkerPool::instance();
+    // 1. many sections, every index exactly once, results visible to the caller afterwards
+    for (int round = 0; round < 3000; ++round) {
+        const unsigned n = 1u + (unsigned)(round * 7 % 61);
+        std::vector<int> hit(n, 0);
+        std::atomic<unsigned> sum{0};
+        pool.run(n, 1u + (unsigned)(round % 16), [&](unsigned t) {
+            hit[t] += 1;
+            sum.fetch_add(t + 1, std::memory_order_relaxed);
+        });
+        unsigned want = 0;
+        for (unsigned t = 0; t < n; ++t) {
+            if (hit[t] != 1) { std::printf("round %d: task %u ran %d times\n", round, t, hit[t]); return 1; }
+            want += t + 1;
+        }
+        if (sum.load() != want) { std::printf("round %d: sum %u != %u\n", round, sum.load(), want); return 1; }
+    }
+    // 2. a section inside a section (runs inline on the worker that asked)
+    std::atomic<unsigned> inner{0};
+    pool.run(8, 8, [&](unsigned) { pool.run(5, 4, [&](unsigned) { inner.fetch_add(1); }); });
+    if (inner.load() != 40) { std::printf("nested: %u != 40\n", inner.load()); return 1; }
+    // 3. concurrent callers: whoever finds the pool busy does its own work
+    std::atomic<unsigned> total{0};
+    std::vector<std::thread> callers;
+    for (int c = 0; c < 6; ++c)
+        callers.emplace_back([&]() {
+            for (int r = 0; r < 400; ++r) pool.run(9, 4, [&](unsigned) { total.fetch_add(1, std::memory_order_relaxed); });
+        });
+    for (auto& t : callers) t.join();
+    if (total.load() != 6u * 400u * 9u) { std::printf("concurrent: %u\n", total.load()); return 1; }
+    std::printf("worker pool OK\n");
+    return 0;
+}

@@ -29,3 +29,13 @@ def test_cpp_mirror_search(cpp_binary, tmp_path):
     r = subprocess.run([cpp_binary, "gpu", str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gpu mode OK" in r.stdout
+
+
+def test_worker_pool_stress(tmp_path):
+    """csrc/worker_pool.hpp by itself (host-only): exactly-once task execution over thousands of sections, nested and
+    concurrent sections without deadlock."""
+    out = tmp_path / "test_worker_pool"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "hnswlib-rs_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "cpp", "test_worker_pool.cpp"), "-o", str(out)], check=True, capture_output=True)
+    r = subprocess.run([str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "worker pool OK" in r.stdout, r.stdout + r.stderr

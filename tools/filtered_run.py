@@ -21,7 +21,8 @@ import torch  # noqa: E402,F401  (first: see INTEGRATION.md, loading order)
 import hnsw_rs_amd as H  # noqa: E402
 
 cfg = bench.CONFIGS[args.config]
-marks = sorted(glob.glob(os.path.join(args.cache_dir, f"bench_{args.config}_*.done")))
+marks = sorted(f for f in glob.glob(os.path.join(args.cache_dir, f"bench_{args.config}_*.done"))
+               if len(os.path.basename(f)) == len(f"bench_{args.config}_") + 12 + 5)  # (12 hex digits: not glove25_dot for glove25)
 if not marks:
     raise SystemExit("run bench.py for this config first (it builds and caches the index)")
 base = os.path.basename(marks[-1])[:-5]

@@ -24,7 +24,8 @@ ap.add_argument("--batches", type=int, default=8)
 ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
 args = ap.parse_args()
 cfg = bench.CONFIGS[args.config]
-dumps = sorted(glob.glob(os.path.join(args.cache_dir, f"bench_{args.config}_*.done")))
+dumps = sorted(f for f in glob.glob(os.path.join(args.cache_dir, f"bench_{args.config}_*.done"))
+               if len(os.path.basename(f)) == len(f"bench_{args.config}_") + 12 + 5)  # (12 hex digits: not glove25_dot for glove25)
 if not dumps:
     sys.exit(f"no cached graph for {args.config} in {args.cache_dir}: run bench.py --config {args.config} first")
 base = os.path.basename(dumps[-1])[:-5]
