@@ -18,7 +18,7 @@ for cfg in sift1m glove25 glove25_dot mnist784 random10k; do
 done
 stamp "N = 2 as a plain command (both ranks on the one device)"
 timeout 400 python bench.py --gpus 2 --share-device --backend nccl --nq 5000 --steps 10 --warmup 2 --no-cpu-baseline --no-recall \
-    > $O/bench_sift1m_n2_shared_device.json 2> $O/bench_sift1m_n2_shared_device.log
+    2> $O/bench_sift1m_n2_shared_device.log | grep '^{' > $O/bench_sift1m_n2_shared_device.json
 python -c "
 import json
 j=[json.loads(l) for l in open('$O/bench_sift1m_n2_shared_device.json') if l.startswith('{')][-1]
