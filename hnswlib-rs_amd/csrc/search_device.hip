@@ -580,6 +580,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (per_cu < 1) per_cu = 1;
         if (const char* e = std::getenv("HNSWGPU_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // tuning hook
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
+        if (std::getenv("HNSWGPU_TRACE_LAUNCH"))  // diagnostics: what bounds the resident workgroups of this launch
+            std::fprintf(stderr, "[hnswgpu launch] %u queries, %d workgroups per CU, %zu bytes of LDS each (literal heap: %u entries), table 2^%u cells, strict %d\n",
+                         work, per_cu, lds, a.cand_lds, a.tbits, (int)strict_kernel);
         a.queries = w.qpad.as<float>();
         a.qlist = qlist;
         a.nq = work;
