@@ -4,6 +4,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -20,6 +21,8 @@ public:
     }
     // Runs fn(0) .. fn(n_tasks - 1), the caller taking part, on at most max_threads threads; returns when all are done.
     // A pool that is busy with another caller's section (or a section started from inside one) runs the tasks on the caller.
+    // A task that throws does not take the process down on a helper thread: the section is still run to its end (the
+    // remaining tasks included) and the first exception is rethrown here, on the caller.
     void run(unsigned n_tasks, unsigned max_threads, const std::function<void(unsigned)>& fn) {
         if (n_tasks == 0) return;
         std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
@@ -47,10 +50,16 @@ public:
         }
         cv_.notify_all();
         work(fn, n_tasks);
-        std::unique_lock<std::mutex> g(mu_);
-        job_open_ = 0;  // late wakers find the section closed
-        done_cv_.wait(g, [this]() { return job_left_ == 0; });
-        job_fn_ = nullptr;
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            job_open_ = 0;  // late wakers find the section closed
+            done_cv_.wait(g, [this]() { return job_left_ == 0; });
+            job_fn_ = nullptr;
+            err = err_;
+            err_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 
 private:
@@ -59,7 +68,12 @@ private:
         for (;;) {
             const unsigned t = job_next_.fetch_add(1, std::memory_order_relaxed);
             if (t >= n) break;
-            fn(t);
+            try {
+                fn(t);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!err_) err_ = std::current_exception();
+            }
         }
     }
     void loop() {
@@ -93,6 +107,7 @@ private:
     unsigned job_n_ = 0, job_open_ = 0, job_left_ = 0;
     std::atomic<unsigned> job_next_{0};
     uint64_t generation_ = 0;
+    std::exception_ptr err_;  // first exception of the running section (guarded by mu_)
     const unsigned limit_;
 };
 

@@ -3,6 +3,7 @@
 // inside a section and sections from concurrent callers run inline instead of deadlocking.
 #include <atomic>
 #include <cstdio>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -41,6 +42,23 @@ int main() {
         });
     for (auto& t : callers) t.join();
     if (total.load() != 6u * 400u * 9u) { std::printf("concurrent: %u\n", total.load()); return 1; }
+    // 4. a task that throws: the other tasks of the section still run, the exception arrives on the caller, the pool lives on
+    for (int round = 0; round < 200; ++round) {
+        std::atomic<unsigned> ran{0};
+        bool caught = false;
+        try {
+            pool.run(24, 8, [&](unsigned t) {
+                ran.fetch_add(1, std::memory_order_relaxed);
+                if (t == (unsigned)(round % 24)) throw std::runtime_error("task failed");
+            });
+        } catch (const std::runtime_error&) {
+            caught = true;
+        }
+        if (!caught || ran.load() != 24u) { std::printf("throwing task: caught %d, %u of 24 ran\n", (int)caught, ran.load()); return 1; }
+    }
+    std::atomic<unsigned> after{0};
+    pool.run(16, 8, [&](unsigned) { after.fetch_add(1); });
+    if (after.load() != 16u) { std::printf("after a throwing section: %u != 16\n", after.load()); return 1; }
     std::printf("worker pool OK\n");
     return 0;
 }
