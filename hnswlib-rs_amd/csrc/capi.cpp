@@ -907,6 +907,8 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
     CAPI_GUARD_BEGIN
     if (!api || !api->idx || !data || knbn == 0 || vec_len <= 0) return nullptr;
     hnswgpu_index* idx = api->idx;
+    for (size_t i = 0; i < nb_vec; ++i)
+        if (!data[i]) { fail(HNSWGPU_ERR_ARG, "parallel_search_neighbours_f32: null row pointer"); return nullptr; }
     FfiAnswer ans{nb_vec, knbn, nullptr};
     // the row pointers are gathered straight into pinned staging memory (the reference copies them into Vec<Vec<f32>>,
     // :218-226), the answers are unpacked straight out of it into the slab

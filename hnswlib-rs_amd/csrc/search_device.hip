@@ -708,6 +708,13 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     if (!lease.get()) return ERR_DEVICE;
     Workspace& w = *lease.get();
     hipStream_t stream = w.own_stream;
+    // an error return may leave copies of this call in flight between the staging buffers: they are waited for BEFORE the
+    // workspace goes back to the pool (declared after the lease, destroyed before it)
+    struct DrainStaging {
+        hipStream_t s;
+        bool done = false;
+        ~DrainStaging() { if (!done) (void)hipStreamSynchronize(s); }
+    } drain{stream};
     // one arena on each side for the answers -- ids | dists | rank | layer | counts -- so that they come back in ONE copy
     const uint64_t q_bytes = nq * d * sizeof(float);
     const uint64_t o_ids = 0, o_dists = o_ids + nq * k * sizeof(uint64_t), o_rank = o_dists + nq * k * sizeof(float),
@@ -753,6 +760,7 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     HIP_TRY(hipMemcpyAsync(ho, dout, o_ans_end, hipMemcpyDeviceToHost, stream));
     if (want_status) HIP_TRY(hipMemcpyAsync(ho + o_stat, w.stats.p, nq * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(wait_stream(stream));
+    drain.done = true;
     HostAnswers a{};
     a.ids = reinterpret_cast<const uint64_t*>(ho + o_ids);
     a.dists = reinterpret_cast<const float*>(ho + o_dists);

@@ -195,3 +195,22 @@ def test_datamap_serves_vectors_by_id_without_loading_the_graph(native, oracle, 
     del m
     gc.collect()
     assert np.array_equal(view, X[5])
+
+
+def test_reference_style_symbols_reject_bad_arguments_without_a_device(native):
+    """parallel_search_neighbours_f32 (src/libext.rs:205-254) dereferences every row pointer it is handed; the replacement
+    checks them first and answers with a null pointer + hnswgpu_last_error(), also on a box without a GPU."""
+    import ctypes as C
+    N = native._native
+    L = N.lib()
+    api = L.init_hnsw_f32(8, 16, 6, b"DistL2")
+    assert api
+    row = (C.c_float * 4)(0.1, 0.2, 0.3, 0.4)
+    L.insert_f32(api, 4, row, 7)
+    rows = (C.c_void_p * 2)(C.cast(row, C.c_void_p), None)
+    assert not L.parallel_search_neighbours_f32(api, 2, 4, rows, 3, 8)
+    assert "null row pointer" in N.last_error()
+    assert not L.parallel_search_neighbours_f32(api, 2, 0, rows, 3, 8)   # vec_len <= 0
+    assert not L.parallel_search_neighbours_f32(api, 2, 4, rows, 0, 8)   # knbn == 0
+    L.hnswgpu_free_neighbourhood_vec(None)
+    L.drop_hnsw_f32(api)
