@@ -21,6 +21,8 @@ import oracle_lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="sift1m", choices=sorted(bench.CONFIGS))
 ap.add_argument("--batches", type=int, default=8)
+ap.add_argument("--seed-base", type=lambda v: int(v, 0), default=0xABCD0000, help="batch b is drawn with seed base + b")
+ap.add_argument("--points-as-queries", type=int, default=0, help="this many queries of every batch are stored points (distance 0, duplicates' ties)")
 ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
 args = ap.parse_args()
 cfg = bench.CONFIGS[args.config]
@@ -33,10 +35,14 @@ h = H.HnswIo(args.cache_dir, base).load_hnsw(cfg["dist"])
 h.upload(0)
 o = oracle_lib.OracleHnsw.load(args.cache_dir, base, cfg["dist"])
 k, ef, d, nq = cfg["k"], cfg["ef"], cfg["d"], cfg["nq"]
+dm = H.DataMap.from_hnswdump(args.cache_dir, base) if args.points_as_queries else None
 bad = checked = ties = 0
 t0 = time.time()
 for b in range(args.batches):
-    Q = bench.synth(nq, d, 0xABCD0000 + b, "clustered" if b % 2 == 0 else "uniform")
+    Q = bench.synth(nq, d, args.seed_base + b, "clustered" if b % 2 == 0 else "uniform")
+    if args.points_as_queries:
+        pick = np.random.default_rng(args.seed_base + b).choice(h.get_nb_point(), args.points_as_queries, replace=False)
+        Q[: args.points_as_queries] = np.stack([dm.get_data(int(i)) for i in pick])  # (origin ids of a bench graph are 0 .. n-1)
     if cfg["dist"] == "DistDot":
         Q /= np.linalg.norm(Q, axis=1, keepdims=True)
     res = h.parallel_search_flat(Q, k, ef)
