@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 GPU call 17: the previous expansion's heap operations handed to the literal pop in registers (default), the literal
 # candidate heap kept once it exists (HNSWGPU_EXACT_FIRST=2), and the strict kernel bounded to 5 waves per SIMD (lib_lb5.so).
+# (A record of a measurement: the variants and switches it compares were removed afterwards -- DESIGN.md section 6, "not kept".)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"

@@ -2,6 +2,7 @@
 # Round-3 GPU call 18: literal candidate heap -- stores to its global part fenced only before a load from it, the id row of the
 # entry about to be popped requested before the heap work (default) against the previous form (lib_old.so), the fence alone
 # (lib_fence.so); what a literal pop costs (profiling builds t_old / t_new).
+# (A record of a measurement: the variants and switches it compares were removed afterwards -- DESIGN.md section 6, "not kept".)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"

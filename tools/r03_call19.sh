@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 GPU call 19: wave issue priority (s_setprio) for long searches (one level every HNSWGPU_PRIO_STEP expansions) and for
 # queries that replay their log (HNSWGPU_PRIO_LITERAL).
+# (A record of a measurement: the variants and switches it compares were removed afterwards -- DESIGN.md section 6, "not kept".)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
