@@ -73,10 +73,16 @@ float jensenshannon_ref(const float* a, const float* b, size_t d) {
     return std::sqrt(0.5f * s);
 }
 
+// (function multi-versioning resolves through ifuncs, which run before a sanitizer's runtime is up: plain functions there)
+#if defined(__SANITIZE_THREAD__) || defined(__SANITIZE_ADDRESS__)
+#define HNSW_CLONES
+#else
+#define HNSW_CLONES __attribute__((target_clones("avx2", "default")))
+#endif
 // "fast" mode: 8 vertical accumulators over floor(d/8)*8 elements, horizontal add, scalar tail --
 // the summation order of the crate's simdeez_f (AVX2) build.  Lane arithmetic is independent of
 // the vector width the compiler picks, so both clones return the same bits.
-__attribute__((target_clones("avx2", "default"))) float l2_fast(const float* a, const float* b, size_t d) {
+HNSW_CLONES float l2_fast(const float* a, const float* b, size_t d) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t i = 0;
     for (; i + 8 <= d; i += 8)
@@ -91,7 +97,7 @@ __attribute__((target_clones("avx2", "default"))) float l2_fast(const float* a, 
     }
     return std::sqrt(s);
 }
-__attribute__((target_clones("avx2", "default"))) float dot_fast(const float* a, const float* b, size_t d) {
+HNSW_CLONES float dot_fast(const float* a, const float* b, size_t d) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t i = 0;
     for (; i + 8 <= d; i += 8)
@@ -100,7 +106,7 @@ __attribute__((target_clones("avx2", "default"))) float dot_fast(const float* a,
     for (; i < d; ++i) s += a[i] * b[i];
     return std::max(1.f - s, 0.f);
 }
-__attribute__((target_clones("avx2", "default"))) float l1_fast(const float* a, const float* b, size_t d) {
+HNSW_CLONES float l1_fast(const float* a, const float* b, size_t d) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t i = 0;
     for (; i + 8 <= d; i += 8)
@@ -109,7 +115,7 @@ __attribute__((target_clones("avx2", "default"))) float l1_fast(const float* a, 
     for (; i < d; ++i) s += std::fabs(a[i] - b[i]);
     return s;
 }
-__attribute__((target_clones("avx2", "default"))) float cosine_fast(const float* a, const float* b, size_t d) {
+HNSW_CLONES float cosine_fast(const float* a, const float* b, size_t d) {
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     size_t i = 0;
     for (; i + 4 <= d; i += 4)

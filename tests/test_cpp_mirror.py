@@ -39,3 +39,40 @@ def test_worker_pool_stress(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "test_worker_pool.cpp"), "-o", str(out)], check=True, capture_output=True)
     r = subprocess.run([str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "worker pool OK" in r.stdout, r.stdout + r.stderr
+
+
+def _tsan_build(tmp_path, name, sources):
+    """g++ -fsanitize=thread; skips when the toolchain has no ThreadSanitizer runtime or the box cannot run one (address-space
+    layouts the runtime does not know make every instrumented program die at start-up)."""
+    probe_src, probe = tmp_path / "tsan_probe.cpp", tmp_path / "tsan_probe"
+    probe_src.write_text("#include <cstdio>\nint main() { std::puts(\"probe ok\"); return 0; }\n")
+    r = subprocess.run(["g++", "-fsanitize=thread", "-pthread", str(probe_src), "-o", str(probe)], capture_output=True, text=True)
+    if r.returncode != 0 or subprocess.run([str(probe)], capture_output=True, text=True).stdout.strip() != "probe ok":
+        pytest.skip("ThreadSanitizer is not usable here")
+    out = tmp_path / name
+    csrc = os.path.join(ROOT, "hnswlib-rs_amd", "csrc")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I", csrc, *sources, "-o", str(out)],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr
+    return str(out)
+
+
+def test_host_builder_is_clean_under_thread_sanitizer(tmp_path):
+    """parallel_insert on the host cores (csrc/builder.cpp): searches read neighbour lists without a lock while other threads
+    rewrite them (EdgeList: a publish-once buffer behind an atomic pointer, reclaimed when the builder dies).  A data race
+    there would be a torn list in a search; ThreadSanitizer must have nothing to report over two batches on 8 threads."""
+    csrc = os.path.join(ROOT, "hnswlib-rs_amd", "csrc")
+    exe = _tsan_build(tmp_path, "test_builder_tsan", [os.path.join(ROOT, "tests", "cpp", "test_builder_tsan.cpp"),
+                                                      os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "hnswio.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"))
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "builder under tsan OK" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_worker_pool_is_clean_under_thread_sanitizer(tmp_path):
+    exe = _tsan_build(tmp_path, "test_worker_pool_tsan", [os.path.join(ROOT, "tests", "cpp", "test_worker_pool.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "worker pool OK" in r.stdout, r.stdout + r.stderr[-2000:]
