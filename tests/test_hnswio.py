@@ -214,3 +214,63 @@ def test_reference_style_symbols_reject_bad_arguments_without_a_device(native):
     assert not L.parallel_search_neighbours_f32(api, 2, 4, rows, 0, 8)   # knbn == 0
     L.hnswgpu_free_neighbourhood_vec(None)
     L.drop_hnsw_f32(api)
+
+
+def _mutate(rng, blob):
+    """one random corruption of a file image: byte flips (half of them in the header), truncation, an extreme 4/8-byte
+    field, inserted garbage"""
+    b = bytearray(blob)
+    mode = rng.random()
+    if mode < 0.45:
+        for _ in range(rng.randint(1, 6)):
+            pos = rng.randrange(min(len(b), 256)) if rng.random() < 0.5 else rng.randrange(len(b))
+            b[pos] = rng.randrange(256)
+    elif mode < 0.65:
+        del b[rng.randrange(len(b)):]
+    elif mode < 0.85:
+        pos, w = rng.randrange(max(1, len(b) - 8)), rng.choice([4, 8])
+        val = rng.choice([0, 1, 0xFFFFFFFF, 0x7FFFFFFF, 0xFFFFFFFFFFFFFFFF, 0x8000000000000000, 1 << 40])
+        b[pos:pos + w] = (val & ((1 << (8 * w)) - 1)).to_bytes(w, "little")
+    else:
+        pos = rng.randrange(len(b))
+        b[pos:pos] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 64)))
+    return bytes(b)
+
+
+def test_mutated_dumps_never_crash_the_reader(tmp_path):
+    """The dump format is the boundary's input side (src/hnswio.rs:937-1340): 400 corrupted copies of the committed fixtures go
+    through load_dump / load_description / write_dump of csrc/hnswio.cpp built with AddressSanitizer + UBSan.  Every one is
+    either rejected with an error code or loaded; none may read out of bounds, overflow or abort."""
+    import random
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "hnswlib-rs_amd", "csrc")
+    exe = tmp_path / "fuzz_hnswio"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread",
+                        "-I", csrc, os.path.join(root, "tests", "cpp", "fuzz_hnswio.cpp"), os.path.join(csrc, "hnswio.cpp"),
+                        os.path.join(csrc, "datamap.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr.lower():
+        pytest.skip("no AddressSanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr
+    gold = os.path.join(root, "tests", "golden")
+    names = sorted(f[:-len(".hnsw.graph")] for f in os.listdir(gold) if f.endswith(".hnsw.graph"))
+    rng = random.Random(20260927)
+    work = tmp_path / "work"
+    work.mkdir()
+    bases = []
+    for it in range(400):
+        nm = rng.choice(names)
+        g = open(os.path.join(gold, nm + ".hnsw.graph"), "rb").read()
+        d = open(os.path.join(gold, nm + ".hnsw.data"), "rb").read()
+        if rng.random() < 0.7:
+            g = _mutate(rng, g)
+        else:
+            d = _mutate(rng, d)
+        (work / f"f{it}.hnsw.graph").write_bytes(g)
+        (work / f"f{it}.hnsw.data").write_bytes(d)
+        bases.append(f"f{it}")
+    r = subprocess.run([str(exe), str(work)], input="\n".join(bases) + "\n", capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "rejected" in r.stdout and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    rejected = int(r.stdout.split("rejected")[1].split()[0])
+    assert rejected > 200          # most corruptions are noticed (the rest hit bytes whose value is free: vector data, distances)
