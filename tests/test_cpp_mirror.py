@@ -76,3 +76,31 @@ def test_worker_pool_is_clean_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0 and "worker pool OK" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def _window_logic_sources():
+    csrc = os.path.join(ROOT, "hnswlib-rs_amd", "csrc")
+    return [os.path.join(ROOT, "tests", "cpp", "test_builder_window_logic.cpp"), os.path.join(csrc, "builder.cpp"), os.path.join(csrc, "hnswio.cpp")]
+
+
+def test_gpu_assisted_construction_host_side_against_a_mock_device(tmp_path):
+    """GraphBuilder::insert_batch_gpu with the device replaced by a CPU mock that keeps the frozen snapshot and searches it with
+    the builder's own semantics: window 1 == the serial insertion (dumps byte-identical), growing windows on several threads,
+    a backend that fails at its third window (the host builder finishes, the call says so), a backend that refuses (index
+    unchanged).  The device side of the same protocol is GPU-tested (tests/test_gpu_round2.py, tests/test_gpu_round3.py)."""
+    exe = tmp_path / "test_builder_window_logic"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "hnswlib-rs_amd", "csrc"),
+                    *_window_logic_sources(), "-o", str(exe)], check=True, capture_output=True)
+    out = tmp_path / "dumps"
+    out.mkdir()
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "window logic OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_gpu_assisted_construction_host_side_is_clean_under_thread_sanitizer(tmp_path):
+    exe = _tsan_build(tmp_path, "test_builder_window_logic_tsan", ["-ffp-contract=off", *_window_logic_sources()])
+    out = tmp_path / "dumps"
+    out.mkdir()
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=900)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "window logic OK" in r.stdout, r.stdout + r.stderr[-2000:]
