@@ -34,6 +34,7 @@ struct EdgeGreaterT {
 
 class HostMockBackend : public BuildSearchBackend {
 public:
+    bool do_select = false;    // run select_neighbours here as well when the builder asks for it (WindowSelect::on_device)
     int fail_at_window = -1;   // search_window number (0-based) that reports a device failure
     bool refuse = false;       // check() refuses
     int windows = 0;
@@ -69,11 +70,11 @@ public:
         records_patched += n_records;
         return OK;
     }
-    int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask, const WindowSelect&,
+    int search_window(uint32_t first, uint32_t count, uint32_t entry, uint32_t entry_level, uint32_t layer_mask, const WindowSelect& wsel,
                       WindowSearchResults& out, std::string& err) override {
         if (windows++ == fail_at_window) { err = "mock: device lost"; return ERR_DEVICE; }
         out = WindowSearchResults();
-        out.selected = false;  // select_neighbours stays with the host in this mock
+        out.selected = do_select && wsel.on_device;  // else select_neighbours stays with the host
         out.slot0.resize(count);
         out.hit_ids.assign((size_t)count * NB_LAYER_MAX, NO_POINT);
         out.hit_d.assign((size_t)count * NB_LAYER_MAX, 0.f);
@@ -82,10 +83,17 @@ public:
             out.slot0[wi] = slots;
             slots += std::min<uint32_t>(levels_[first + wi], entry_level) + 1u;
         }
-        out.out_ids.assign((size_t)slots * efc_, NO_POINT);
-        out.out_d.assign((size_t)slots * efc_, 0.f);
-        out.out_n.assign(slots, 0u);
-        std::vector<Edge> res;
+        if (out.selected) {
+            out.sel_stride = std::max(wsel.nb_layer0, wsel.nb_upper);
+            out.sel_ids.assign((size_t)slots * out.sel_stride, NO_POINT);
+            out.sel_d.assign((size_t)slots * out.sel_stride, 0.f);
+            out.sel_n.assign(slots, 0u);
+        } else {
+            out.out_ids.assign((size_t)slots * efc_, NO_POINT);
+            out.out_d.assign((size_t)slots * efc_, 0.f);
+            out.out_n.assign(slots, 0u);
+        }
+        std::vector<Edge> res, sel;
         for (uint32_t wi = 0; wi < count; ++wi) {
             const uint32_t id = first + wi;
             const unsigned level = levels_[id];
@@ -103,10 +111,30 @@ public:
                 // (a layer counts as populated for this point when it is its own level: generate_new_point pushed it first)
                 search(q, enter, efc_, (unsigned)l, ((layer_mask >> l) & 1u) != 0u || (unsigned)l == level, res);
                 const size_t slot = (size_t)out.slot0[wi] + (size_t)l;
-                out.out_n[slot] = (uint32_t)res.size();
-                for (size_t j = 0; j < res.size(); ++j) {
-                    out.out_ids[slot * efc_ + j] = res[j].id;
-                    out.out_d[slot * efc_ + j] = res[j].dist;
+                if (out.selected) {  // select_neighbours (src/hnsw.rs:1299-1421; no extension, no kept pruned entries here)
+                    const size_t nb = l == 0 ? wsel.nb_layer0 : wsel.nb_upper;
+                    sel.clear();
+                    if (res.size() <= nb) {
+                        sel = res;
+                    } else {
+                        for (size_t i = 0; i < res.size() && sel.size() < nb; ++i) {
+                            bool keep = true;
+                            for (const Edge& s : sel)
+                                if (l2(vec(res[i].id), vec(s.id)) <= res[i].dist) { keep = false; break; }
+                            if (keep) sel.push_back(res[i]);
+                        }
+                    }
+                    out.sel_n[slot] = (uint32_t)sel.size();
+                    for (size_t j = 0; j < sel.size(); ++j) {
+                        out.sel_ids[slot * out.sel_stride + j] = sel[j].id;
+                        out.sel_d[slot * out.sel_stride + j] = sel[j].dist;
+                    }
+                } else {
+                    out.out_n[slot] = (uint32_t)res.size();
+                    for (size_t j = 0; j < res.size(); ++j) {
+                        out.out_ids[slot * efc_ + j] = res[j].id;
+                        out.out_d[slot * efc_ + j] = res[j].dist;
+                    }
                 }
                 if (!res.empty()) enter = res[0].id;  // select_neighbours keeps the nearest candidate first
             }
@@ -210,12 +238,13 @@ int main(int argc, char** argv) {
     const uint64_t d = 10;
     std::string err;
     // ---- 1. window = 1 is the serial insertion
-    {
+    for (int pass = 0; pass < 2; ++pass) {
         const uint64_t n = 1500;
         const std::vector<float> x = data_set(n, d, 11);
         GraphBuilder serial(params()), windowed(params());
         if (serial.insert_batch(x.data(), n, d, nullptr, 1, err) != OK) { std::printf("serial: %s\n", err.c_str()); return 1; }
         HostMockBackend dev;
+        dev.do_select = pass == 1;  // second pass: select_neighbours on the "device" too
         if (windowed.insert_batch_gpu(x.data(), n, d, nullptr, 1, dev, 1, err) != OK) { std::printf("window 1: %s\n", err.c_str()); return 1; }
         if (!windowed.last_warning().empty()) { std::printf("window 1: unexpected warning %s\n", windowed.last_warning().c_str()); return 1; }
         FlatIndex a, b;
@@ -236,6 +265,7 @@ int main(int argc, char** argv) {
         HostMockBackend dev;
         if (b.insert_batch_gpu(x.data(), 6000, d, nullptr, 8, dev, 0, err) != OK) { std::printf("windows: %s\n", err.c_str()); return 1; }
         HostMockBackend dev2;
+        dev2.do_select = true;
         if (b.insert_batch_gpu(x.data() + 6000 * d, n - 6000, d, nullptr, 8, dev2, 512, err) != OK) { std::printf("windows, second batch: %s\n", err.c_str()); return 1; }
         FlatIndex f;
         b.finalize(f);
