@@ -1,0 +1,33 @@
+// Stand-in for search_device.hip on a box without HIP: every device entry reports "no device" (what the product library does
+// there, too) -- so that the host side of the C ABI (capi.cpp, builder.cpp, hnswio.cpp, datamap.cpp) can be built with
+// AddressSanitizer and driven by the CPU test-suite.  Test infrastructure only.
+#include "search_device.hpp"
+#include "hnswio.hpp"
+namespace hnswgpu {
+struct DeviceIndex::Workspace {};
+static const char* kNoDev = "no HIP device visible (a gfx950 GPU is required; there is no CPU fallback)";
+DeviceIndex::DeviceIndex() {}
+DeviceIndex::~DeviceIndex() {}
+int DeviceIndex::upload(const FlatIndex&, int, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+int DeviceIndex::search_device(const float*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*, uint32_t*,
+                               void*, const uint64_t*, uint64_t, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+int DeviceIndex::search_host(const float*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*,
+                             const uint64_t*, uint64_t, bool, uint8_t*, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+int DeviceIndex::search_host_staged(const float*, const float* const*, uint64_t, uint64_t, uint64_t, uint64_t, const uint64_t*, uint64_t, bool,
+                                    bool, AnswerSink, void*, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+CallInfo DeviceIndex::last_call() const { return CallInfo{}; }
+int device_count() { return 0; }
+namespace {
+class NoDeviceBackend : public BuildSearchBackend {
+public:
+    int check(uint64_t, std::string& err) override { err = kNoDev; return ERR_DEVICE; }
+    int begin(const float* const*, uint64_t, uint64_t, uint64_t, const uint8_t*, int, uint64_t, uint64_t, unsigned, uint64_t, std::string& err) override { err = kNoDev; return ERR_DEVICE; }
+    uint32_t rec_words() const override { return 2; }
+    uint32_t* patch_buffer(uint64_t, std::string& err) override { err = kNoDev; return nullptr; }
+    int patch(uint64_t, std::string& err) override { err = kNoDev; return ERR_DEVICE; }
+    int search_window(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const WindowSelect&, WindowSearchResults&, std::string& err) override { err = kNoDev; return ERR_DEVICE; }
+};
+}  // namespace
+std::unique_ptr<BuildSearchBackend> make_device_build_backend(int) { return std::unique_ptr<BuildSearchBackend>(new NoDeviceBackend()); }
+int eval_distance_matrix_device(int, const float*, uint64_t, const float*, uint64_t, uint64_t, uint32_t, bool, float*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+}  // namespace hnswgpu
