@@ -232,3 +232,104 @@ def test_probability_distances_follow_the_formulas_step_by_step(oracle):
         assert oracle.dist_eval("DistJensenShannon", a, b) == f(np.sqrt(f(f(0.5) * s), dtype=f))
     for dist in ("DistHellinger", "DistJeffreys", "DistJensenShannon"):
         assert abs(oracle.dist_eval(dist, P[0], P[0])) < 4e-4     # d(p, p) = 0 (Hellinger: up to the rounding of sum sqrt(p)^2)
+
+
+class _StdBinaryHeap:
+    """A second, independent transcription of Rust std's `BinaryHeap` (alloc/collections/binary_heap.rs), written from the
+    algorithm's published description and kept apart from oracle/hnsw_oracle.hpp on purpose: `push` = append + `sift_up`
+    (stop at `elt <= parent`), `pop` = swap-remove the root with the last element, `sift_down_to_bottom` (always down to a
+    leaf, taking the right child when `left <= right`), then `sift_up`; `into_sorted_vec` = repeated swap of root and end
+    with `sift_down_range` (stop at `elt >= child`; a lone last child is taken when `elt < child`).  Entries are
+    (key, tag); only the key is compared."""
+
+    def __init__(self):
+        self.d = []
+
+    def _sift_up(self, start, pos):
+        elt = self.d[pos]
+        while pos > start:
+            parent = (pos - 1) // 2
+            if elt[0] <= self.d[parent][0]:
+                break
+            self.d[pos] = self.d[parent]
+            pos = parent
+        self.d[pos] = elt
+        return pos
+
+    def push(self, item):
+        self.d.append(item)
+        self._sift_up(0, len(self.d) - 1)
+
+    def pop(self):
+        if not self.d:
+            return None
+        item = self.d.pop()
+        if self.d:
+            item, self.d[0] = self.d[0], item
+            end, pos = len(self.d), 0
+            elt = self.d[0]
+            child = 1
+            while child <= max(end, 2) - 2 and end >= 2:
+                if self.d[child][0] <= self.d[child + 1][0]:
+                    child += 1
+                self.d[pos] = self.d[child]
+                pos = child
+                child = 2 * pos + 1
+            if child == end - 1:
+                self.d[pos] = self.d[child]
+                pos = child
+            self.d[pos] = elt
+            self._sift_up(0, pos)
+        return item
+
+    def into_sorted_vec(self):
+        d = self.d
+        end = len(d)
+        while end > 1:
+            end -= 1
+            d[0], d[end] = d[end], d[0]
+            pos, elt = 0, d[0]
+            child = 1
+            moved = False
+            while child <= max(end, 2) - 2 and end >= 2:
+                if d[child][0] <= d[child + 1][0]:
+                    child += 1
+                if elt[0] >= d[child][0]:
+                    d[pos] = elt
+                    moved = True
+                    break
+                d[pos] = d[child]
+                pos = child
+                child = 2 * pos + 1
+            if not moved:
+                if child == end - 1 and elt[0] < d[child][0]:
+                    d[pos] = d[child]
+                    pos = child
+                d[pos] = elt
+        return d
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_two_transcriptions_of_std_binary_heap_agree(oracle, seed):
+    """Random scripts of pushes and pops over FEW distinct keys (ties everywhere, tags tell equal keys apart): the oracle's C++
+    `RustBinaryHeap` and the Python transcription above must pop the same tags in the same order and leave the same
+    `into_sorted_vec`.  Not a pin (both are restatements), but a transcription slip in either shows up here."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(50, 900))
+    levels = int(rng.choice([2, 3, 5, 17, 1000]))
+    vals = (rng.integers(0, levels, n) / np.float32(levels)).astype(np.float32)
+    tags = np.arange(n, dtype=np.int32)
+    is_pop = (rng.random(n) < rng.choice([0.15, 0.35, 0.5])).astype(np.uint8)
+    pv, pt, sv, st = oracle.heap_script(vals, tags, is_pop)
+    h = _StdBinaryHeap()
+    popped = []
+    for i in range(n):
+        if is_pop[i]:
+            x = h.pop()
+            if x is not None:
+                popped.append(x)
+        else:
+            h.push((float(vals[i]), int(tags[i])))
+    rest = h.into_sorted_vec()
+    assert [t for _, t in popped] == list(pt) and np.array_equal(np.array([v for v, _ in popped], np.float32), pv)
+    assert [t for _, t in rest] == list(st) and np.array_equal(np.array([v for v, _ in rest], np.float32), sv)
