@@ -387,8 +387,12 @@ def main():
     if world > 1:
         seen = torch.ones(1, dtype=torch.int64, device=coll_dev)
         dist_pg.all_reduce(seen)  # every rank of the group adds one: the ranks this communicator really spans
+        try:
+            rccl_version = "RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 -- informational only
+            rccl_version = "RCCL"
         rccl = {"backend": dist_pg.get_backend(), "requested": args.backend, "ranks_seen": int(seen.item()),
-                "library": ("RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())) if backend_used == "nccl" else "gloo (host tensors)",
+                "library": rccl_version if backend_used == "nccl" else "gloo (host tensors)",
                 "fallback_reason": fallback_reason, "devices": "all ranks on HIP device 0 (--share-device)" if args.share_device else "one HIP device per rank"}
 
     cfg = dict(CONFIGS[args.config])
@@ -446,20 +450,20 @@ def main():
     Q = Qh[0]
     Qds = [torch.from_numpy(q).to(dev) for q in Qh]
     Qd = Qds[0]
-    out_ids = torch.zeros((nq_local, k), dtype=torch.int64, device=dev)
-    out_dists = torch.zeros((nq_local, k), dtype=torch.float32, device=dev)
+    # the answers of a rank live side by side in ONE byte buffer (ids | distances | counts): the search writes the collective's
+    # send buffer in place and the exchange is ONE all-gather per step (hnsw_rs_amd.sharded)
+    from hnsw_rs_amd.sharded import AnswerGather, PackedAnswers
+    packed = PackedAnswers(nq_local, k, dev)
+    out_ids, out_dists, out_counts = packed.ids, packed.dists, packed.counts
     out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
     out_rank = torch.zeros((nq_local, k), dtype=torch.int32, device=dev)
-    out_counts = torch.zeros((nq_local,), dtype=torch.int32, device=dev)
     stats = torch.zeros((nq_local, 8), dtype=torch.int32, device=dev)
-    if world > 1:
-        gathered_ids = torch.empty((nq_total, k), dtype=torch.int64, device=coll_dev)
-        gathered_dists = torch.empty((nq_total, k), dtype=torch.float32, device=coll_dev)
-        gathered_counts = torch.empty((nq_total,), dtype=torch.int32, device=coll_dev)
+    gatherer = AnswerGather(nq_total, k, world, coll_dev) if world > 1 else None
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
     main_ms = []
+    gather_marks = []  # per step: (event before, event after) the all-gather on the launch stream, or host seconds (gloo)
 
     def step(i):
         rc = lib.hnswgpu_search_batch_device(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, out_ids.data_ptr(),
@@ -470,10 +474,17 @@ def main():
         ms, _ = index.last_kernel_ms()  # HIP events on the launch stream, inside the library
         kernel_ms.append(ms)
         main_ms.append(index.last_search_kernel_ms())
-        if world > 1:  # the only exchange on this path: gather of the answers (RCCL over xGMI)
-            dist_pg.all_gather_into_tensor(gathered_ids, out_ids.to(coll_dev))
-            dist_pg.all_gather_into_tensor(gathered_dists, out_dists.to(coll_dev))
-            dist_pg.all_gather_into_tensor(gathered_counts, out_counts.to(coll_dev))
+        if world > 1:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
+            if backend_used == "nccl":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                gatherer.gather(packed)
+                e1.record(stream)
+                gather_marks.append((e0, e1))
+            else:
+                t0 = time.perf_counter()
+                gatherer.gather(packed)
+                gather_marks.append(time.perf_counter() - t0)
 
     def fence():
         if world > 1:
@@ -497,11 +508,15 @@ def main():
         step(i)
     kernel_ms.clear()
     main_ms.clear()
+    gather_marks.clear()
     elapsed = timed(args.steps)
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq_total * args.steps / elapsed
     timed_main_ms = list(main_ms)
     timed_kernel_ms = list(kernel_ms)
+    gather_ms = None
+    if world > 1 and gather_marks:  # (the stream is idle: timed() ended with a synchronize)
+        gather_ms = float(np.mean([m[0].elapsed_time(m[1]) if isinstance(m, tuple) else m * 1e3 for m in gather_marks]))
 
     # untimed accounting: one more step per batch for its work counters (the algorithmic bytes of that batch)
     batch_stats = []
@@ -571,7 +586,8 @@ def main():
     fence()
     if args.dump_answers and rank == 0:  # batch 0 in input order: what the caller of parallel_search gets back
         if world > 1:
-            np.savez(args.dump_answers, ids=gathered_ids.cpu().numpy(), dists=gathered_dists.cpu().numpy(), counts=gathered_counts.cpu().numpy())
+            g_ids, g_dists, g_counts = gatherer.in_input_order()
+            np.savez(args.dump_answers, ids=g_ids.cpu().numpy(), dists=g_dists.cpu().numpy(), counts=g_counts.cpu().numpy())
         else:
             np.savez(args.dump_answers, ids=out_ids.cpu().numpy(), dists=out_dists.cpu().numpy(), counts=out_counts.cpu().numpy())
 
@@ -608,11 +624,19 @@ def main():
     if args.dump_stats and rank == 0:
         np.save(args.dump_stats, st)
 
-    def alg_bytes_of(sb):
-        # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded
-        return int(sb[:, 0].sum()) * d * 4 + int(sb[:, 2].sum()) * 4 + int(sb[:, 1].sum()) * 8 + nq_local * (d * 4 + k * 12)
+    def alg_bytes_of(sb, part="search"):
+        # bytes = n_dist*d*4 + n_ids_read*4 + n_expand*8 + d*4 + k*12 per query, d unpadded.  The greedy descent
+        # of a query runs in hnsw_descend_kernel, in front of the search kernel: stats word 7 says what of the counters is
+        # its share (lists scanned << 8 | n_dist << 16), and the dominant kernel is priced on its own share only.
+        nd_desc, nx_desc = (sb[:, 7] >> 16) & 0xFFFF, (sb[:, 7] >> 8) & 0xFF
+        desc = int(nd_desc.sum()) * d * 4 + int((nd_desc - 1).clip(min=0).sum()) * 4 + int(nx_desc.sum()) * 8 + nq_local * d * 4
+        if part == "descent":
+            return desc
+        total = int(sb[:, 0].sum()) * d * 4 + int(sb[:, 2].sum()) * 4 + int(sb[:, 1].sum()) * 8 + nq_local * (d * 4 + k * 12)
+        return total - (desc - nq_local * d * 4)  # (the search kernel stages the query row as well)
 
     batch_bytes = [alg_bytes_of(sb) for sb in batch_stats]
+    descent_bytes = float(np.mean([alg_bytes_of(sb, "descent") for sb in batch_stats]))
     n_dist, n_expand, n_ids = (int(sum(sb[:, c].sum() for sb in batch_stats)) / NB for c in (0, 1, 2))
     # the dominant kernel is hnsw_search_kernel (queries that need the literal heaps carry on inside it); achieved =
     # algorithmic bytes of the batches the timed steps searched / the kernel time of those launches (HIP events)
@@ -639,6 +663,10 @@ def main():
                 "traffic": None, "traffic_from_profile": traffic_profile,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
                 "all_kernels_ms": round(all_ms, 4),
+                # in front of the search kernel on the same stream: hnsw_descend_kernel (queries padded + the greedy descent of
+                # every query, exact arithmetic) and order_desc_kernel (longest searches first)
+                "descent_and_order_kernels": {"ms": round(all_ms - k_ms, 4), "algorithmic_bytes_per_launch": int(descent_bytes),
+                                              "note": "their bytes and their time are NOT in achieved / kernel_ms: the dominant kernel is priced on its own share"},
                 "queries_resolved_with_literal_heaps": int((st[:, 3] == 3).sum()),
                 "queries_that_met_equal_distances": int((st[:, 7] & 1).sum()),
                 "launches_per_step": index.last_kernel_ms()[1], "query_batches_rotated": NB,
@@ -670,9 +698,11 @@ def main():
             "config": {"workload": cfg["label"], "n": n, "d": d, "distance": cfg["dist"], "M": cfg["M"],
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
                        "queries_total": nq_total, "graph": "replicated per GPU",
-                       "exchange": ("all_gather of the answers (ids, distances, counts) over %s" % ("RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
+                       "exchange": ("one all_gather_into_tensor per step of the packed answers (ids | distances | counts, %d bytes per rank) over %s"
+                                    % (gatherer.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
                        "parallelism": f"{world} x (replica + {nq_local} queries)"},
             "rccl": rccl,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 4),
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
             "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},

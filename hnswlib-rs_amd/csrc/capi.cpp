@@ -18,6 +18,7 @@
 #include "flat_index.hpp"
 #include "hnswio.hpp"
 #include "search_device.hpp"
+#include "worker_pool.hpp"
 
 using namespace hnswgpu;
 
@@ -610,10 +611,11 @@ int hnswgpu_search_batch_device(const hnswgpu_index* cidx, const float* d_querie
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
 }
 
-// begin / end: the blocking call on a worker thread of its own (searches on one handle may run concurrently, each with
-// a private workspace), so the launch path is the one every other entry point uses
+// begin / end: the blocking call as an asynchronous job of the library's worker pool (a long-lived thread: creating one per
+// ticket cost tens of microseconds on a ~1 ms call), so the launch path is the one every other entry point uses; searches on
+// one handle may run concurrently, each with a private workspace
 struct hnswgpu_ticket {
-    std::thread worker;
+    std::shared_ptr<WorkerPool::Job> job;
     int status = HNSWGPU_OK;
     std::string error;
 };
@@ -627,7 +629,7 @@ int hnswgpu_search_batch_device_begin(const hnswgpu_index* cidx, const float* d_
     if (!cidx) return fail(HNSWGPU_ERR_ARG, "null index");
     std::unique_ptr<hnswgpu_ticket> t(new hnswgpu_ticket());
     hnswgpu_ticket* raw = t.get();
-    raw->worker = std::thread([=]() {
+    raw->job = WorkerPool::instance().submit([=]() {
         raw->status = hnswgpu_search_batch_device(cidx, d_queries, nq, d, k, ef, d_out_ids, d_out_dists, d_out_layer, d_out_rank,
                                                   d_out_counts, d_stats, stream);
         if (raw->status != HNSWGPU_OK) raw->error = hnswgpu_last_error();  // this thread's message, handed to the ticket
@@ -640,7 +642,7 @@ int hnswgpu_search_batch_end(hnswgpu_ticket* ticket) {
     CAPI_GUARD_BEGIN
     if (!ticket) return fail(HNSWGPU_ERR_ARG, "null ticket");
     std::unique_ptr<hnswgpu_ticket> t(ticket);
-    if (t->worker.joinable()) t->worker.join();
+    if (t->job) t->job->wait();
     if (t->status != HNSWGPU_OK) return fail(t->status, t->error);
     return HNSWGPU_OK;
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
@@ -900,6 +902,46 @@ struct FfiAnswer {
     size_t nq, k;
     Vec_api_Neighbourhood* out;
 };
+// A caller that frees its answers (hnswgpu_free_neighbourhood_vec) and asks again gets the same memory back: a 10 000 x 10
+// answer is a 1.9 MB allocation, which malloc serves with mmap / munmap and the kernel with ~470 fresh page faults per call --
+// a tenth of a millisecond on a 1.2 ms search.  A few freed slabs (at most 64 MB) are kept for the next call of the same size.
+class SlabCache {
+public:
+    void* take(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = 0; i < n_; ++i)
+                if (slab_[i].bytes == bytes) {
+                    void* p = slab_[i].p;
+                    slab_[i] = slab_[--n_];
+                    held_ -= bytes;
+                    return p;
+                }
+        }
+        return std::malloc(bytes);
+    }
+    void give(void* p, size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (n_ < KEEP && held_ + bytes <= (64ull << 20)) {
+                slab_[n_++] = Entry{p, bytes};
+                held_ += bytes;
+                return;
+            }
+        }
+        std::free(p);
+    }
+private:
+    struct Entry { void* p; size_t bytes; };
+    static constexpr size_t KEEP = 4;
+    std::mutex mu_;
+    Entry slab_[KEEP] = {};
+    size_t n_ = 0, held_ = 0;
+};
+SlabCache& slab_cache() {
+    static SlabCache* c = new SlabCache();  // (never destroyed: answers may be freed during static destruction)
+    return *c;
+}
 }  // namespace
 
 const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* api, size_t nb_vec, int64_t vec_len,
@@ -916,7 +958,7 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
         FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
         const size_t bytes = sizeof(SlabHeader) + sizeof(Vec_api_Neighbourhood) + f.nq * sizeof(Neighbourhood_api) +
                              f.nq * f.k * sizeof(Neighbour_api);
-        unsigned char* slab = static_cast<unsigned char*>(std::malloc(bytes));
+        unsigned char* slab = static_cast<unsigned char*>(slab_cache().take(bytes));
         if (!slab) return;
         SlabHeader* h = reinterpret_cast<SlabHeader*>(slab);
         h->magic = SLAB_MAGIC;
@@ -924,16 +966,22 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
         Vec_api_Neighbourhood* v = reinterpret_cast<Vec_api_Neighbourhood*>(slab + sizeof(SlabHeader));
         Neighbourhood_api* lists = reinterpret_cast<Neighbourhood_api*>(v + 1);
         Neighbour_api* rows = reinterpret_cast<Neighbour_api*>(lists + f.nq);
-        for (size_t i = 0; i < f.nq; ++i) {
-            const uint32_t c = a.counts[i];
-            Neighbour_api* r = rows + i * f.k;
-            for (uint32_t j = 0; j < c; ++j) {
-                r[j].id = (size_t)a.ids[i * f.k + j];
-                r[j].d = a.dists[i * f.k + j];
+        // (a few pool threads: the rows are written once, 16 bytes per neighbour, out of the pinned arena)
+        const unsigned nt = f.nq * f.k < (1u << 14) ? 1u : (unsigned)std::min<size_t>(8, f.nq / 1024 + 1);
+        const size_t per = (f.nq + nt - 1) / nt;
+        WorkerPool::instance().run(nt, nt, [&](unsigned t) {
+            const size_t b = std::min(f.nq, (size_t)t * per), e = std::min(f.nq, ((size_t)t + 1) * per);
+            for (size_t i = b; i < e; ++i) {
+                const uint32_t c = a.counts[i];
+                Neighbour_api* r = rows + i * f.k;
+                for (uint32_t j = 0; j < c; ++j) {
+                    r[j].id = (size_t)a.ids[i * f.k + j];
+                    r[j].d = a.dists[i * f.k + j];
+                }
+                lists[i].nbgh = (int64_t)c;
+                lists[i].neighbours = r;
             }
-            lists[i].nbgh = (int64_t)c;
-            lists[i].neighbours = r;
-        }
+        });
         v->len = (int64_t)f.nq;
         v->ptr = lists;
         f.out = v;
@@ -970,16 +1018,14 @@ void hnswgpu_free_neighbourhood(const Neighbourhood_api* p) {
     std::free(const_cast<Neighbour_api*>(p->neighbours));
     std::free(const_cast<Neighbourhood_api*>(p));
 }
+// Every Vec_api this library hands out is the head of ONE slab (header | Vec_api | Neighbourhood_api[] | Neighbour_api[]): the
+// rows are interior pointers and must never be freed one by one; the whole answer is released here, and only here.
 void hnswgpu_free_neighbourhood_vec(const Vec_api_Neighbourhood* p) {
     if (!p) return;
-    const SlabHeader* h = reinterpret_cast<const SlabHeader*>(reinterpret_cast<const unsigned char*>(p) - sizeof(SlabHeader));
-    if (h->magic == SLAB_MAGIC) {  // (every Vec_api this library hands out is the head of one slab)
-        std::free(const_cast<SlabHeader*>(h));
-        return;
-    }
-    for (int64_t i = 0; i < p->len; ++i) std::free(const_cast<Neighbour_api*>(p->ptr[i].neighbours));
-    std::free(const_cast<Neighbourhood_api*>(p->ptr));
-    std::free(const_cast<Vec_api_Neighbourhood*>(p));
+    SlabHeader* h = reinterpret_cast<SlabHeader*>(reinterpret_cast<unsigned char*>(const_cast<Vec_api_Neighbourhood*>(p)) - sizeof(SlabHeader));
+    const uint64_t bytes = h->bytes;
+    h->magic = 0;  // (a second free of the same answer is then at least not taken for a slab by the cache)
+    slab_cache().give(h, (size_t)bytes);
 }
 
 int64_t file_dump_f32(const HnswApif32* api, size_t namelen, const uint8_t* filename) {

@@ -38,16 +38,6 @@ namespace hnswgpu {
 
 namespace {
 
-// queries [nq][d] -> [nq][row_stride] zero padded
-__global__ void pad_queries_kernel(const float* __restrict__ src, float* __restrict__ dst, uint32_t nq, uint32_t d,
-                                   uint32_t row_stride) {
-    const size_t total = (size_t)nq * row_stride;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)(i / row_stride), c = (uint32_t)(i % row_stride);
-        dst[i] = c < d ? src[(size_t)r * d + c] : 0.f;
-    }
-}
-
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -97,6 +87,8 @@ private:
     hipError_t status_ = hipSuccess;
 };
 
+constexpr int STRICT_WG_PER_CU = 16;  // resident workgroups per CU of a strict launch: four waves per SIMD (see search_device)
+
 uint32_t ceil_log2(uint64_t x) {
     uint32_t b = 0;
     while ((1ull << b) < x) ++b;
@@ -142,29 +134,35 @@ struct DevBuf {
 
 // everything one search call writes: taken from the replica's pool for the duration of the call
 // pinned host memory grown on demand (staging of the host-buffer entry points)
+// (mapped: the kernels of a host-buffer search read the queries from it and write the answers into it across PCIe --
+// nothing is staged in HBM; dev = the same memory as the device addresses it)
 struct PinnedBuf {
     void* p = nullptr;
+    void* dev = nullptr;
     uint64_t cap = 0;
     hipError_t ensure(uint64_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
+        free();
         const uint64_t want = std::max<uint64_t>(bytes, 1u << 16);
-        const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocPortable);
         if (e != hipSuccess) { p = nullptr; return e; }
+        e = hipHostGetDevicePointer(&dev, p, 0);
+        if (e != hipSuccess) { (void)hipHostFree(p); p = nullptr; dev = nullptr; return e; }
         cap = want;
         return hipSuccess;
     }
+    // staging memory of an unusually large batch is given back when its workspace returns to the pool
+    void trim(uint64_t keep_bytes) { if (cap > keep_bytes) free(); }
     void free() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
     }
 };
 
 struct DeviceIndex::Workspace {
-    DevBuf qpad, tie, predist, order, retry[2], stats, bitmap, heaps, cand, oplog, allow, allowed_ids, hostio[2];
+    DevBuf qpad, tie, pre, order, retry[2], stats, bitmap, heaps, cand, oplog, allow, allowed_ids;
     PinnedBuf pin_in, pin_out;
     void* d_ctrl = nullptr;   // work counter + counters
     void* h_ctrl = nullptr;   // pinned host copy (read back once per launch)
@@ -181,8 +179,7 @@ struct DeviceIndex::Workspace {
         return OK;
     }
     ~Workspace() {
-        for (DevBuf* b : {&qpad, &tie, &predist, &order, &retry[0], &retry[1], &stats, &bitmap, &heaps, &cand, &oplog, &allow,
-                          &allowed_ids, &hostio[0], &hostio[1]})
+        for (DevBuf* b : {&qpad, &tie, &pre, &order, &retry[0], &retry[1], &stats, &bitmap, &heaps, &cand, &oplog, &allow, &allowed_ids})
             b->free();
         pin_in.free();
         pin_out.free();
@@ -222,6 +219,9 @@ DeviceIndex::Workspace* DeviceIndex::acquire(std::string& err) {
     return all_ws_.back().get();
 }
 void DeviceIndex::release_ws(Workspace* w) {
+    // pinned staging memory only ever grew: a single 100 000 x 784 batch left hundreds of MB pinned on every pooled workspace
+    w->pin_in.trim(64ull << 20);
+    w->pin_out.trim(64ull << 20);
     std::lock_guard<std::mutex> g(pool_mu_);
     free_ws_.push_back(w);
 }
@@ -270,6 +270,7 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     device_ = device;
     dist_ = x.dist;
     bytes_ = 0;
+    descend_per_cu_.store(0);
 
     const uint64_t n = x.n, d = x.dimension;
     DeviceIndexView v{};
@@ -393,6 +394,7 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
     a.out_rank = d_out_rank;
     a.out_counts = d_out_counts;
     a.stats = stats;
+    a.pre = w.pre.as<PreDescent>();
     ExactArgs x{};
     x.heaps = w.heaps.as<hent_t>();
     x.heap_stride = heap_stride;
@@ -417,7 +419,7 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
 int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_arg,
                                uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank,
                                uint32_t* d_out_counts, uint32_t* d_stats, void* stream_v, const uint64_t* d_allowed,
-                               uint64_t n_allowed, CallInfo* info_out, std::string& err) {
+                               uint64_t n_allowed, CallInfo* info_out, std::string& err, const RowFeed* feed) {
     if (!ready_) { err = "index is not resident on a device: call hnswgpu_upload first"; return ERR_DEVICE; }
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
     CallInfo info{};
@@ -452,13 +454,35 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     uint32_t* stats = d_stats ? d_stats : w.stats.as<uint32_t>();
     const bool strict_ties = strict_ties_.load();
 
+    HIP_TRY(w.pre.ensure(nq * sizeof(PreDescent)));
+    const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
     HIP_TRY(hipEventRecord(w.ev_start, stream));
-    // pad queries to the row stride (tiny, stays on the launch stream)
+    // first kernel of the call: rows padded to the row stride, the greedy descent of every query (pre[]), counters zeroed
     {
-        const uint64_t total = nq * v_.row_stride;
-        const int blocks = (int)std::min<uint64_t>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(pad_queries_kernel, dim3(blocks), dim3(256), 0, stream, d_queries, w.qpad.as<float>(), (uint32_t)nq, v_.d,
-                           v_.row_stride);
+        const KernelSet& ks = kernel_set(dist_);
+        int per_cu = descend_per_cu_.load();
+        if (per_cu <= 0) {
+            HIP_TRY(ks.descend_occupancy(tile_bytes + IDS_BYTES, &per_cu));
+            per_cu = std::max(1, per_cu);
+            descend_per_cu_.store(per_cu);
+        }
+        // one launch -- or, when the rows are still being gathered into pinned memory, one per chunk: the device reads chunk i
+        // across PCIe while the host fills chunk i + 1 (a few chunks: every launch costs a few microseconds of stream time)
+        const uint64_t chunk = feed ? std::max<uint64_t>(1024, (nq + 3) / 4) : nq;
+        for (uint64_t lo = 0; lo < nq; lo += chunk) {
+            const uint64_t hi = std::min(nq, lo + chunk);
+            if (feed) feed->fill(feed->ctx, lo, hi);
+            DescendArgs da{};
+            da.src = d_queries + lo * v_.d;
+            da.qpad = w.qpad.as<float>() + lo * v_.row_stride;
+            da.pre = w.pre.as<PreDescent>() + lo;
+            da.nq = (uint32_t)(hi - lo);
+            da.tile_bytes = tile_bytes;
+            da.nrm2 = static_cast<const double*>(d_nrm2_);
+            da.ctrl = lo == 0 ? static_cast<uint32_t*>(w.d_ctrl) : nullptr;
+            da.ctrl_words = 16;
+            HIP_TRY(ks.launch_descend((uint32_t)std::min<uint64_t>(hi - lo, (uint64_t)per_cu * (uint64_t)num_cu_), stream, v_, da));
+        }
     }
 
     // ---- filtered search, and ef beyond the register-resident result set (64 x 16 entries): literal heaps in memory
@@ -510,24 +534,16 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (b >= 6 && b <= 14) { tbits = (uint32_t)b; env_forced = true; }
     }
     const uint32_t tbits_first = tbits;
-    const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
     const size_t lds_fixed = tile_bytes + IDS_BYTES;
     int table = TABLE_LDS_CELL16;
     bool grown = false;
 
-    // Batch scheduling: the searches run in descending order of the (estimated) distance to the layer-0 entry point,
-    // long searches first (DESIGN.md "scheduling").  Small batches skip it (one launch, lowest latency).
+    // Batch scheduling: the searches run in descending order of the distance to the layer-0 entry point (the descent's
+    // result), long searches first (DESIGN.md "scheduling").  Small batches skip it (one launch less, lowest latency).
     const bool scheduled = nq >= 256 && !std::getenv("HNSWGPU_NO_SCHED");
     if (scheduled) {
-        HIP_TRY(w.predist.ensure(nq * sizeof(float)));
         HIP_TRY(w.order.ensure(nq * sizeof(uint32_t)));
-        SearchArgs da{};
-        da.queries = w.qpad.as<float>();
-        da.nq = (uint32_t)nq;
-        da.pre_dist = w.predist.as<float>();
-        const uint32_t dgrid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)num_cu_ * 24u);
-        HIP_TRY(kernel_set(dist_).launch_estimate(dgrid, stream, v_, da));
-        HIP_TRY(kernel_set(dist_).launch_order(stream, w.predist.as<float>(), (uint32_t)nq, w.order.as<uint32_t>()));
+        HIP_TRY(kernel_set(dist_).launch_order(stream, w.pre.as<PreDescent>(), (uint32_t)nq, w.order.as<uint32_t>()));
     }
     uint32_t launches = 0, stop_recorded_after = ~0u;
     uint32_t work = (uint32_t)nq;
@@ -572,12 +588,17 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
                 int occ256 = 0, occ512 = 0;
                 HIP_TRY(ks.occupancy(slots, table, true, lds + 256 * sizeof(hent_t), &occ256));
                 HIP_TRY(ks.occupancy(slots, table, true, lds + 512 * sizeof(hent_t), &occ512));
-                if (occ512 >= occ256) a.cand_lds = 512;
+                if (std::min(occ512, STRICT_WG_PER_CU) >= std::min(occ256, STRICT_WG_PER_CU)) a.cand_lds = 512;
             }
             lds += (size_t)a.cand_lds * sizeof(hent_t);
         }
         HIP_TRY(ks.occupancy(slots, table, strict_kernel, lds, &per_cu));
         if (per_cu < 1) per_cu = 1;
+        // A strict launch ends with its longest search -- normally one that replayed its heap-operation log -- and a fifth wave
+        // per SIMD slows every expansion of it: with the descent out of the kernel the strict kernel needs 89 VGPRs and would
+        // fit 20 workgroups per CU; measured (config 2, one box) 7.63 M queries/s at 20, 8.49 M at 16.  The lean kernel gains
+        // from its 20 (9.7 M) and keeps them.
+        if (strict_kernel) per_cu = std::min(per_cu, STRICT_WG_PER_CU);
         if (const char* e = std::getenv("HNSWGPU_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // tuning hook
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
         if (std::getenv("HNSWGPU_TRACE_LAUNCH"))  // diagnostics: what bounds the resident workgroups of this launch
@@ -597,6 +618,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         a.out_rank = d_out_rank;
         a.out_counts = d_out_counts;
         a.stats = stats;
+        a.pre = w.pre.as<PreDescent>();
         {
             // HBM bitmaps for the in-launch fallback: one slice per workgroup, within a 4 GiB budget
             a.bitmap_words = (v_.n + 31) / 32;
@@ -620,7 +642,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             a.oplog_cap = cap;
             if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;  // test hook
         }
-        HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, launches == 0 ? 32 : 16, stream));  // the flagged list spans relaunches
+        // (the first launch finds the counters zeroed by the descent kernel; the flagged list spans relaunches)
+        if (launches != 0) HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, 16, stream));
         if (launches == 0) HIP_TRY(hipEventRecord(w.ev_ks, stream));
         HIP_TRY(ks.launch_search(slots, table, strict_kernel, grid, lds, stream, v_, a));
         if (launches == 0) HIP_TRY(hipEventRecord(w.ev_ke, stream));
@@ -715,52 +738,66 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         bool done = false;
         ~DrainStaging() { if (!done) (void)hipStreamSynchronize(s); }
     } drain{stream};
-    // one arena on each side for the answers -- ids | dists | rank | layer | counts -- so that they come back in ONE copy
+    // Nothing is staged in HBM: the queries are gathered into MAPPED pinned memory, which the descent kernel reads across PCIe
+    // while it pads them (the H2D copy disappears into a pass that runs anyway), and the search kernels write the answers --
+    // ids | dists | rank | layer | counts, 1.7 MB for 10 000 x 10 -- straight into a pinned arena the sink reads.  (Rounds 2-3:
+    // gather -> H2D copy -> pad kernel ... -> D2H copy, every step waiting for the one before.)
+    const bool trace = std::getenv("HNSWGPU_TRACE_HOST") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    };
     const uint64_t q_bytes = nq * d * sizeof(float);
     const uint64_t o_ids = 0, o_dists = o_ids + nq * k * sizeof(uint64_t), o_rank = o_dists + nq * k * sizeof(float),
                    o_layer = o_rank + nq * k * sizeof(int32_t), o_cnt = (o_layer + nq * k + 7) & ~7ull,
                    o_ans_end = o_cnt + nq * sizeof(uint32_t), o_stat = (o_ans_end + 7) & ~7ull,
                    o_end = o_stat + (want_status ? nq * 8 * sizeof(uint32_t) + nq : 0);
-    HIP_TRY(w.hostio[0].ensure(q_bytes));
-    HIP_TRY(w.hostio[1].ensure(o_ans_end));
-    HIP_TRY(w.stats.ensure(nq * 8 * sizeof(uint32_t)));
     HIP_TRY(w.pin_in.ensure(q_bytes));
     HIP_TRY(w.pin_out.ensure(o_end));
     float* hq = static_cast<float*>(w.pin_in.p);
     unsigned char* ho = static_cast<unsigned char*>(w.pin_out.p);
-    float* dq = w.hostio[0].as<float>();
-    unsigned char* dout = w.hostio[1].as<unsigned char>();
-    uint64_t* dids = reinterpret_cast<uint64_t*>(dout + o_ids);
-    float* ddist = reinterpret_cast<float*>(dout + o_dists);
-    int32_t* drank = reinterpret_cast<int32_t*>(dout + o_rank);
-    uint8_t* dlayer = dout + o_layer;
-    uint32_t* dcnt = reinterpret_cast<uint32_t*>(dout + o_cnt);
+    unsigned char* dout = static_cast<unsigned char*>(w.pin_out.dev);  // the same arena as the device addresses it
     const uint64_t* dallowed = nullptr;
     if (filtered) {
         HIP_TRY(w.allowed_ids.ensure(std::max<uint64_t>(1, n_allowed) * sizeof(uint64_t)));
         if (n_allowed) HIP_TRY(hipMemcpyAsync(w.allowed_ids.p, allowed, n_allowed * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         dallowed = w.allowed_ids.as<uint64_t>();
     }
-    // gather (contiguous matrix or row pointers) into pinned memory on a few pool threads, then one asynchronous copy
-    // (gathering in pieces with a copy behind each was measured: the extra dispatches cost more than the overlap gives)
-    {
-        const uint64_t row_bytes = d * sizeof(float);
-        if (queries) {
-            parallel_chunks(nq, row_bytes, [&](uint64_t b, uint64_t e) { std::memcpy(hq + b * d, queries + b * d, (e - b) * row_bytes); });
-        } else {
-            parallel_chunks(nq, row_bytes, [&](uint64_t b, uint64_t e) {
-                for (uint64_t i = b; i < e; ++i) std::memcpy(hq + i * d, rows[i], row_bytes);
-            });
-        }
-        HIP_TRY(hipMemcpyAsync(dq, hq, q_bytes, hipMemcpyHostToDevice, stream));
-    }
-    int rc = search_device(dq, nq, d, k, ef, dids, ddist, dlayer, drank, dcnt, w.stats.as<uint32_t>(), stream, dallowed,
-                           filtered ? n_allowed : 0, info, err);
+    // gather (contiguous matrix or row pointers) into pinned memory on a few pool threads, chunk by chunk from inside
+    // search_device: the descent kernel of chunk i reads it across PCIe while chunk i + 1 is gathered
+    struct Feed {
+        const float* queries;
+        const float* const* rows;
+        float* hq;
+        uint64_t d;
+        double us = 0.;
+    } fd{queries, rows, hq, d};
+    RowFeed feed{[](void* ctx, uint64_t lo, uint64_t hi) {
+                     Feed& f = *static_cast<Feed*>(ctx);
+                     const auto t0 = std::chrono::steady_clock::now();
+                     const uint64_t row_bytes = f.d * sizeof(float);
+                     if (f.queries) {
+                         parallel_chunks(hi - lo, row_bytes, [&](uint64_t b, uint64_t e) {
+                             std::memcpy(f.hq + (lo + b) * f.d, f.queries + (lo + b) * f.d, (e - b) * row_bytes);
+                         });
+                     } else {
+                         parallel_chunks(hi - lo, row_bytes, [&](uint64_t b, uint64_t e) {
+                             for (uint64_t i = lo + b; i < lo + e; ++i) std::memcpy(f.hq + i * f.d, f.rows[i], row_bytes);
+                         });
+                     }
+                     f.us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                 },
+                 &fd};
+    const auto t_search = std::chrono::steady_clock::now();
+    int rc = search_device(static_cast<const float*>(w.pin_in.dev), nq, d, k, ef, reinterpret_cast<uint64_t*>(dout + o_ids),
+                           reinterpret_cast<float*>(dout + o_dists), dout + o_layer, reinterpret_cast<int32_t*>(dout + o_rank),
+                           reinterpret_cast<uint32_t*>(dout + o_cnt), want_status ? reinterpret_cast<uint32_t*>(dout + o_stat) : nullptr,
+                           stream, dallowed, filtered ? n_allowed : 0, info, err, &feed);
+    const double us_gather = fd.us;
     if (rc != OK) return rc;
-    HIP_TRY(hipMemcpyAsync(ho, dout, o_ans_end, hipMemcpyDeviceToHost, stream));
-    if (want_status) HIP_TRY(hipMemcpyAsync(ho + o_stat, w.stats.p, nq * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(wait_stream(stream));
-    drain.done = true;
+    drain.done = true;  // (search_device returns with the stream idle: the answers are in the arena)
+    const double us_search = since(t_search);
+    const auto t_sink = std::chrono::steady_clock::now();
     HostAnswers a{};
     a.ids = reinterpret_cast<const uint64_t*>(ho + o_ids);
     a.dists = reinterpret_cast<const float*>(ho + o_dists);
@@ -774,6 +811,9 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         a.status = flags;
     }
     sink(ctx, a);
+    if (trace)
+        std::fprintf(stderr, "[hnswgpu host call] %llu queries: %.0f us in all; gather into pinned memory %.0f us (in chunks, inside:) search %.0f us, "
+                     "answers out of the pinned arena %.0f us\n", (unsigned long long)nq, since(t_begin), us_gather, us_search, since(t_sink));
     return OK;
 }
 

@@ -59,10 +59,17 @@ public:
     // Hnsw::parallel_search on device-resident buffers.  d_queries: nq x d row-major.
     // d_allowed != nullptr: Hnsw::search_filter with the sorted id vector d_allowed[0..n_allowed) (device memory) for
     // every query of the batch (src/hnsw.rs:1487-1580, src/filter.rs:11-15).
+    // feed (may be null): d_queries is mapped pinned host memory that is still being filled -- fill(ctx, lo, hi) makes rows
+    // [lo, hi) valid; the call then gathers and launches the descent kernel chunk by chunk, so that the device reads chunk i
+    // across PCIe while the host gathers chunk i + 1 (the host-buffer entry points).
+    struct RowFeed {
+        void (*fill)(void* ctx, uint64_t lo, uint64_t hi);
+        void* ctx;
+    };
     int search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                       float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
                       uint32_t* d_stats, void* stream, const uint64_t* d_allowed, uint64_t n_allowed, CallInfo* info,
-                      std::string& err);
+                      std::string& err, const RowFeed* feed = nullptr);
     // same with host buffers (H2D + kernels + D2H); out_status (may be null): per query, 1 = the reference panics
     int search_host(const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids,
                     float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
@@ -124,6 +131,7 @@ private:
     uint32_t adapt_tbits_ = 0;
     CallInfo last_{};
     std::atomic<bool> strict_ties_{true};
+    std::atomic<int> descend_per_cu_{0};  // resident workgroups per CU of the descent kernel (asked once)
 };
 
 int device_count();

@@ -18,6 +18,24 @@ constexpr uint32_t IDS_BYTES = 64 * 4;  // LDS: the compacted ids of one batch o
 
 typedef unsigned long long hent_t;  // heap / log entry: {key f32 (high), id u32 (low)}
 
+// the greedy descent of one query (hnsw_descend_kernel): where its search_layer starts
+struct PreDescent {
+    uint32_t pivot;      // entry point of the search layer (flat id)
+    uint32_t dcur_bits;  // its distance to the query (f32 bit pattern; >= 0, so the patterns order like the values)
+    uint32_t n_dist;     // distance evaluations of the descent (ids read = n_dist - 1)
+    uint32_t n_expand;   // lists scanned
+};
+struct DescendArgs {
+    const float* src;    // [nq][d] the caller's queries, unpadded (device memory, or pinned host memory read across PCIe)
+    float* qpad;         // [nq][row_stride] zero padded copy for the search kernels
+    PreDescent* pre;     // [nq]
+    uint32_t nq;
+    uint32_t tile_bytes;
+    const double* nrm2;  // as in SearchArgs
+    uint32_t* ctrl;      // the call's counters, zeroed by workgroup 0 (ctrl_words of them, <= 64)
+    uint32_t ctrl_words;
+};
+
 struct SearchArgs {
     const float* queries;   // [nq][row_stride], zero padded
     const uint32_t* qlist;  // optional: indices of the queries to run (scheduling order / retry pass), else nullptr
@@ -50,8 +68,9 @@ struct SearchArgs {
     uint8_t* out_layer;
     int32_t* out_rank;
     uint32_t* out_counts;
-    float* pre_dist;        // hnsw_estimate_kernel: [nq] estimated distance to the layer-0 entry point (scheduling key)
-    uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used, flags
+    const PreDescent* pre;  // [nq_total] what hnsw_descend_kernel left for every query: entry point of the search layer, its distance
+    uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used,
+                            // flags | (lists scanned by the descent << 8) | (n_dist of the descent << 16)
 };
 
 struct ExactArgs {
@@ -122,10 +141,11 @@ struct KernelSet {
     hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);
     hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
                                const SearchArgs& a, const ExactArgs& x);
-    // batch scheduling: estimated distance of every query to its layer-0 entry point, then the queries in descending
-    // order of it
-    hipError_t (*launch_estimate)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const SearchArgs& a);
-    hipError_t (*launch_order)(hipStream_t stream, const float* keys, uint32_t n, uint32_t* order);
+    // first kernel of a call: queries padded, greedy descent of every query (pre[]); then, batch scheduling, the queries in
+    // descending order of the descent's distance
+    hipError_t (*launch_descend)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const DescendArgs& a);
+    hipError_t (*descend_occupancy)(size_t lds, int* per_cu);
+    hipError_t (*launch_order)(hipStream_t stream, const PreDescent* pre, uint32_t n, uint32_t* order);
     // arithmetic tests: out[q][r] = dist(queries[q], rows[r]) through batch_dist, rows in batches of nf; or, pairs:
     // out[q] = dist(queries[q], rows[q])
     hipError_t (*launch_eval_matrix)(hipStream_t stream, const float* queries, uint32_t nq, const float* rows, uint32_t n_rows,

@@ -1,14 +1,21 @@
-// worker_pool.hpp -- a few long-lived host threads for the short parallel sections of the library (staging copies of a
-// host-buffer search, the host side of a construction window).  Creating std::threads per section costs more than some of the
-// sections themselves (three sections per window, ~100 windows per build; two per search call).
+// worker_pool.hpp -- long-lived host threads for the parallel sections of the library (staging copies of a host-buffer
+// search, the host side of a construction window, a whole host build) and for its asynchronous calls (tickets).  Creating
+// std::threads per section costs more than some of the sections themselves (three sections per window, ~100 windows per
+// build; two per search call).
+//
+// Sections of different callers share the threads: every section queues "invitations" for helpers, idle threads take them in
+// arrival order, and the caller always works on its own section -- so a section never waits for a thread (it is at worst run
+// by its caller alone while the helpers are busy elsewhere, and helpers that come free join it late), sections may be nested,
+// and a long section (a 48 s host build) does not turn every other one into a serial loop.
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
-#include <vector>
 
 namespace hnswgpu {
 
@@ -19,96 +26,165 @@ public:
         static WorkerPool* p = new WorkerPool();
         return *p;
     }
-    // Runs fn(0) .. fn(n_tasks - 1), the caller taking part, on at most max_threads threads; returns when all are done.
-    // A pool that is busy with another caller's section (or a section started from inside one) runs the tasks on the caller.
-    // A task that throws does not take the process down on a helper thread: the section is still run to its end (the
-    // remaining tasks included) and the first exception is rethrown here, on the caller.
+    // the most helper threads a section can get (the caller comes on top).  A section gets the thread count it asks for, also
+    // beyond the hardware threads of the box (oversubscription is the caller's choice: the race tests rely on it); threads
+    // are created on demand and then kept.
+    unsigned max_helpers() const { return cap_; }
+
+    // Runs fn(0) .. fn(n_tasks - 1), the caller taking part, on at most max_threads threads (capped at max_helpers() + 1);
+    // returns when all are done.  A task that throws does not take the process down on a helper thread: the section is still
+    // run to its end (the remaining tasks included) and the first exception is rethrown here, on the caller.
     void run(unsigned n_tasks, unsigned max_threads, const std::function<void(unsigned)>& fn) {
         if (n_tasks == 0) return;
-        std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
-        if (n_tasks == 1 || max_threads <= 1 || !busy.owns_lock()) {
+        if (n_tasks == 1 || max_threads <= 1) {
             for (unsigned t = 0; t < n_tasks; ++t) fn(t);
             return;
         }
-        const unsigned helpers = std::min(std::min(n_tasks, max_threads) - 1u, limit_);
+        Section s;
+        s.fn = &fn;
+        s.n = n_tasks;
+        const unsigned helpers = std::min(std::min(n_tasks, max_threads) - 1u, cap_);
         {
             std::lock_guard<std::mutex> g(mu_);
-            while (threads_.size() < helpers) {
-                try {
-                    threads_.emplace_back([this]() { loop(); });
-                    threads_.back().detach();
-                } catch (...) {
-                    break;  // no more threads to be had: the ones there are (and the caller) do the work
-                }
-            }
-            job_fn_ = &fn;
-            job_n_ = n_tasks;
-            job_next_.store(0, std::memory_order_relaxed);
-            job_open_ = std::min<unsigned>(helpers, (unsigned)threads_.size());  // helpers that may still join this section
-            job_left_ = 0;                                                       // helpers inside it
-            ++generation_;
+            for (unsigned i = 0; i < helpers; ++i) queue_.push_back(Item{&s, nullptr});
+            s.invited = helpers;
+            grow_locked(helpers);
         }
-        cv_.notify_all();
-        work(fn, n_tasks);
+        if (helpers == 1) cv_.notify_one(); else cv_.notify_all();
+        work(s);
         std::exception_ptr err;
         {
             std::unique_lock<std::mutex> g(mu_);
-            job_open_ = 0;  // late wakers find the section closed
-            done_cv_.wait(g, [this]() { return job_left_ == 0; });
-            job_fn_ = nullptr;
-            err = err_;
-            err_ = nullptr;
+            // invitations nobody took are withdrawn; helpers inside the section are waited for
+            for (auto it = queue_.begin(); it != queue_.end();) {
+                if (it->section == &s) { it = queue_.erase(it); --s.invited; }
+                else ++it;
+            }
+            s.done_cv.wait(g, [&]() { return s.invited == 0; });
+            err = s.err;
         }
         if (err) std::rethrow_exception(err);
     }
 
+    // An asynchronous one-off job (a ticket of the C ABI): runs on a pool thread as soon as one is free -- one is created when
+    // all are busy, so a job never queues behind a long section.  wait() blocks until it has run; a job that throws is the
+    // caller's bug (jobs catch their own errors).
+    class Job {
+    public:
+        void wait() {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [this]() { return done_; });
+        }
+    private:
+        friend class WorkerPool;
+        std::function<void()> fn_;
+        std::mutex mu_;
+        std::condition_variable cv_;
+        bool done_ = false;
+    };
+    std::shared_ptr<Job> submit(std::function<void()> fn) {
+        std::shared_ptr<Job> j(new Job());
+        j->fn_ = std::move(fn);
+        bool queued = false;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (idle_ > 0 || n_threads_ < HARD_CAP) {
+                queue_.push_front(Item{nullptr, j});  // ahead of invitations: a job has no caller working on it
+                if (idle_ == 0) spawn_locked();
+                queued = true;
+            }
+        }
+        if (queued) {
+            cv_.notify_one();
+        } else {  // no thread to be had: run it here rather than never
+            run_job(*j);
+        }
+        return j;
+    }
+
 private:
-    WorkerPool() : limit_(std::max(1u, std::min(63u, std::thread::hardware_concurrency()) ) - 1u) {}
-    void work(const std::function<void(unsigned)>& fn, unsigned n) {
+    struct Section {
+        const std::function<void(unsigned)>* fn = nullptr;
+        unsigned n = 0;
+        std::atomic<unsigned> next{0};
+        unsigned invited = 0;            // invitations queued or taken and not yet finished (guarded by the pool's mu_)
+        std::condition_variable done_cv;
+        std::exception_ptr err;          // first exception (guarded by mu_)
+    };
+    struct Item {
+        Section* section;                // an invitation to help with a section, or
+        std::shared_ptr<Job> job;        // an asynchronous job
+    };
+    static constexpr unsigned HARD_CAP = 1024;  // threads this pool will ever create
+
+    WorkerPool() : cap_(255u) {}
+    void work(Section& s) {
         for (;;) {
-            const unsigned t = job_next_.fetch_add(1, std::memory_order_relaxed);
-            if (t >= n) break;
+            const unsigned t = s.next.fetch_add(1, std::memory_order_relaxed);
+            if (t >= s.n) break;
             try {
-                fn(t);
+                (*s.fn)(t);
             } catch (...) {
                 std::lock_guard<std::mutex> g(mu_);
-                if (!err_) err_ = std::current_exception();
+                if (!s.err) s.err = std::current_exception();
             }
         }
+    }
+    static void run_job(Job& j) {
+        try {
+            j.fn_();
+        } catch (...) {
+        }
+        {
+            std::lock_guard<std::mutex> g(j.mu_);
+            j.done_ = true;
+        }
+        j.cv_.notify_all();
+    }
+    // threads for `wanted` queued invitations beyond what the idle ones can take (sections never create more than cap_
+    // threads in all; jobs may go beyond)
+    void grow_locked(unsigned wanted) {
+        while (idle_ + spawning_ < wanted && n_threads_ < cap_) {
+            if (!spawn_locked()) break;
+        }
+    }
+    bool spawn_locked() {
+        try {
+            std::thread([this]() { loop(); }).detach();
+        } catch (...) {
+            return false;  // no more threads to be had: the ones there are (and the callers) do the work
+        }
+        ++n_threads_;
+        ++spawning_;
+        return true;
     }
     void loop() {
-        uint64_t seen = 0;
+        std::unique_lock<std::mutex> g(mu_);
+        --spawning_;
         for (;;) {
-            const std::function<void(unsigned)>* fn = nullptr;
-            unsigned n = 0;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&]() { return generation_ != seen; });
-                seen = generation_;
-                if (job_open_ == 0) continue;  // the section is full or already over
-                --job_open_;
-                ++job_left_;
-                fn = job_fn_;
-                n = job_n_;
+            ++idle_;
+            cv_.wait(g, [this]() { return !queue_.empty(); });
+            --idle_;
+            Item it = std::move(queue_.front());
+            queue_.pop_front();
+            g.unlock();
+            if (it.job) {
+                run_job(*it.job);
+                it.job.reset();
+                g.lock();
+            } else {
+                Section* s = it.section;
+                work(*s);
+                g.lock();
+                if (--s->invited == 0) s->done_cv.notify_all();  // (the section lives until its caller has seen invited == 0)
             }
-            work(*fn, n);
-            {
-                std::lock_guard<std::mutex> g(mu_);
-                --job_left_;
-            }
-            done_cv_.notify_all();
         }
     }
-    std::mutex run_mu_;   // one section at a time
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    std::vector<std::thread> threads_;
-    const std::function<void(unsigned)>* job_fn_ = nullptr;
-    unsigned job_n_ = 0, job_open_ = 0, job_left_ = 0;
-    std::atomic<unsigned> job_next_{0};
-    uint64_t generation_ = 0;
-    std::exception_ptr err_;  // first exception of the running section (guarded by mu_)
-    const unsigned limit_;
+    std::condition_variable cv_;
+    std::deque<Item> queue_;
+    unsigned n_threads_ = 0, idle_ = 0, spawning_ = 0;
+    const unsigned cap_;
 };
 
 }  // namespace hnswgpu

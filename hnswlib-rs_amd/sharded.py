@@ -2,9 +2,12 @@
 
 The search path has no data-path collective: every query is an independent read-only traversal
 (src/hnsw.rs:1618-1620).  The only exchange is the gather of the answers, done with
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests) as ONE
+collective per batch: a rank's ids, distances and counts live side by side in one byte buffer
+(`PackedAnswers`), which the search writes in place and `all_gather_into_tensor` moves whole -- three
+collectives of 0.1-1 MB each would pay the launch latency of a collective three times on a ~1 ms step.
+`bench.py --gpus N` and the CPU test of the N>1 path (tests/test_sharding.py) both go through this module.
 """
-import numpy as np
 
 
 def shard_bounds(nq, world_size, rank):
@@ -14,32 +17,82 @@ def shard_bounds(nq, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def max_shard_rows(nq, world_size):
+    return (nq + world_size - 1) // world_size
+
+
+class PackedAnswers:
+    """The answers of one shard in ONE contiguous byte buffer: ids i64[rows][k] | dists f32[rows][k] | counts i32[rows]
+    (16-byte padded).  `ids`, `dists`, `counts` are typed views of it: hand their data_ptr() to
+    hnswgpu_search_batch_device and the kernel writes the collective's send buffer directly."""
+
+    def __init__(self, rows, k, device):
+        import torch
+        self.rows, self.k = int(rows), int(k)
+        o_d = self.rows * self.k * 8
+        o_c = o_d + self.rows * self.k * 4
+        self.nbytes = (o_c + self.rows * 4 + 15) // 16 * 16
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.ids, self.dists, self.counts = self.views_of(self.buf, self.rows, self.k)
+
+    @staticmethod
+    def views_of(buf, rows, k):
+        """Typed views (ids, dists, counts) of one packed shard buffer (a 1-D uint8 tensor)."""
+        import torch
+        o_d = rows * k * 8
+        o_c = o_d + rows * k * 4
+        return (buf[:o_d].view(torch.int64).view(rows, k), buf[o_d:o_c].view(torch.float32).view(rows, k),
+                buf[o_c:o_c + rows * 4].view(torch.int32))
+
+
+class AnswerGather:
+    """All-gather of the shards' packed answers: one `all_gather_into_tensor` per call.  `coll_device` is where the
+    group's collectives run (the rank's GPU for nccl/RCCL, the CPU for gloo); a shard buffer that lives elsewhere is
+    copied there first (one copy)."""
+
+    def __init__(self, nq_total, k, world_size, coll_device, group=None):
+        import torch
+        self.nq, self.k, self.world, self.group = int(nq_total), int(k), int(world_size), group
+        self.rows = max_shard_rows(self.nq, self.world)
+        self.shard_bytes = PackedAnswers(0, k, "cpu").nbytes if self.rows == 0 else PackedAnswers(self.rows, k, "cpu").nbytes
+        self.coll_device = torch.device(coll_device)
+        self.recv = torch.empty(self.world * self.shard_bytes, dtype=torch.uint8, device=self.coll_device)
+
+    def gather(self, packed):
+        """packed: this rank's PackedAnswers with `rows` == max_shard_rows (shorter shards leave the tail unused)."""
+        import torch.distributed as dist
+        if packed.rows != self.rows or packed.k != self.k:
+            raise ValueError("PackedAnswers of %d x %d rows, the gather was sized for %d x %d" % (packed.rows, packed.k, self.rows, self.k))
+        send = packed.buf if packed.buf.device == self.coll_device else packed.buf.to(self.coll_device)
+        dist.all_gather_into_tensor(self.recv, send, group=self.group)
+        return self.recv
+
+    def in_input_order(self):
+        """(ids [nq,k], dists [nq,k], counts [nq]) of the last gather, shards put back side by side."""
+        import torch
+        parts = ([], [], [])
+        for r in range(self.world):
+            lo, hi = shard_bounds(self.nq, self.world, r)
+            v = PackedAnswers.views_of(self.recv[r * self.shard_bytes:(r + 1) * self.shard_bytes], self.rows, self.k)
+            for p, t in zip(parts, v):
+                p.append(t[: hi - lo])
+        return tuple(torch.cat(p, dim=0) for p in parts)
+
+
 def gather_answers(local_ids, local_dists, local_counts, nq, group=None):
-    """All-gather the per-shard answers into input order.  Arrays are torch tensors on the group's device
-    (shape [nq_local, k] / [nq_local]); shards may differ in length by one row (padded for the collective)."""
-    import torch
+    """All-gather the per-shard answers into input order (one collective).  Arrays are torch tensors on the group's
+    device (shape [nq_local, k] / [nq_local]); shards may differ in length by one row."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     k = local_ids.shape[1]
-    max_rows = (nq + world - 1) // world
-
-    def pad(t):
-        if t.shape[0] == max_rows:
-            return t.contiguous()
-        out = torch.zeros((max_rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        out[: t.shape[0]] = t
-        return out
-
-    outs = []
-    for t in (local_ids, local_dists, local_counts):
-        buf = [torch.empty_like(pad(t)) for _ in range(world)]
-        dist.all_gather(buf, pad(t), group=group)
-        parts = []
-        for r in range(world):
-            lo, hi = shard_bounds(nq, world, r)
-            parts.append(buf[r][: hi - lo])
-        outs.append(torch.cat(parts, dim=0))
-    return outs  # ids [nq,k], dists [nq,k], counts [nq]
+    g = AnswerGather(nq, k, world, local_ids.device, group)
+    p = PackedAnswers(g.rows, k, local_ids.device)
+    n = local_ids.shape[0]
+    p.ids[:n] = local_ids
+    p.dists[:n] = local_dists
+    p.counts[:n] = local_counts
+    g.gather(p)
+    return list(g.in_input_order())  # ids [nq,k], dists [nq,k], counts [nq]
 
 
 def sharded_parallel_search(search_fn, queries, knbn, ef, group=None):

@@ -210,7 +210,9 @@ int hnswgpu_search_batch_sharded_device(const hnswgpu_index* idx, const int* dev
  * `stream` (hipStream_t as void*; NULL = default stream).  Synchronises `stream` once
  * before returning (the visited-set overflow check needs one 4-byte read-back).
  * d_stats may be NULL, else uint32[nq*8] per query = {n_dist, n_expand, n_ids_read, status,
- * t_start, t_end (device wall clock, 10 ns ticks), used_hbm_bitmap, 0}.
+ * t_start, t_end (device wall clock, 10 ns ticks), used_hbm_bitmap, flags | (lists scanned by the greedy descent << 8) | (its n_dist << 16)}
+ * (flags: 1 equal distances met, 2 a pop was taken from the literal candidate heap; n_dist / n_expand / n_ids_read include
+ * the descent, which runs in a kernel of its own in front of the search kernel; its ids read = its n_dist - 1).
  * status: 0 ok; 2 ok, but the answer depends on the reference's heap order and strict ties are off;
  * 3 ok, resolved with the literal heaps (strict ties; see DESIGN.md "ties").  ef above 1024 (the
  * register-resident result set) is served by the literal-heap kernel: correct, slower.          */
@@ -330,7 +332,12 @@ const DescriptionFFI* load_hnsw_description(size_t flen, const uint8_t* name);  
 void init_rust_log(void);                                                          /* :1238-1240 (no-op) */
 
 /* The reference leaks every result buffer to the caller and exports no free function
- * (SURVEY.md 8b "Ownership").  These are additions.                                       */
+ * (SURVEY.md 8b "Ownership").  These are additions.
+ * hnswgpu_free_neighbourhood releases what search_neighbours_f32 returned (the struct and its row).
+ * hnswgpu_free_neighbourhood_vec releases what parallel_search_neighbours_f32 returned, and is the ONLY way to release
+ * it: the answer is one allocation (Vec_api | Neighbourhood_api[nb_vec] | every Neighbour_api row), so `ptr` and each
+ * `neighbours` are interior pointers -- never free() a row or hand one of its Neighbourhood_api to
+ * hnswgpu_free_neighbourhood, and never pass a Vec_api this library did not return.                                   */
 void hnswgpu_free_neighbourhood(const Neighbourhood_api* p);
 void hnswgpu_free_neighbourhood_vec(const Vec_api_Neighbourhood* p);
 void hnswgpu_free_hnswio(const HnswIo* p);

@@ -1,7 +1,11 @@
 // Stress of csrc/worker_pool.hpp (the long-lived helper threads of the staging copies and of the construction windows):
-// every task index runs exactly once per section, sections of different sizes follow each other, a section started from
-// inside a section and sections from concurrent callers run inline instead of deadlocking.
+// every task index runs exactly once per section, sections of different sizes follow each other, sections started from
+// inside a section and sections of concurrent callers share the helper threads (nobody deadlocks, nobody is silently
+// serialised behind a long section), asynchronous jobs run while a long section occupies the pool.
 #include <atomic>
+#include <chrono>
+#include <set>
+#include <mutex>
 #include <cstdio>
 #include <stdexcept>
 #include <thread>
@@ -55,6 +59,38 @@ int main() {
             caught = true;
         }
         if (!caught || ran.load() != 24u) { std::printf("throwing task: caught %d, %u of 24 ran\n", (int)caught, ran.load()); return 1; }
+    }
+    // 5. a long section does not serialise a second caller's section: while one caller keeps 4 threads busy for a long time,
+    // another caller's section must still be served by more than one thread (the old pool ran it on the
+    // caller alone, silently)
+    if (std::thread::hardware_concurrency() >= 4) {
+        std::atomic<bool> stop{false};
+        std::thread long_caller([&]() {
+            pool.run(4, 4, [&](unsigned) { while (!stop.load(std::memory_order_relaxed)) std::this_thread::yield(); });
+        });
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        std::mutex m;
+        std::set<std::thread::id> who;
+        pool.run(64, 4, [&](unsigned) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            std::lock_guard<std::mutex> g(m);
+            who.insert(std::this_thread::get_id());
+        });
+        stop.store(true);
+        long_caller.join();
+        if (who.size() < 2) { std::printf("a second section next to a long one ran on %zu thread(s)\n", who.size()); return 1; }
+    }
+    // 6. asynchronous jobs (the tickets of the C ABI): they run, wait() returns after them, also while sections keep the pool busy
+    {
+        std::atomic<unsigned> jobs_done{0};
+        std::atomic<bool> stop{false};
+        std::thread busy([&]() { pool.run(8, 8, [&](unsigned) { while (!stop.load(std::memory_order_relaxed)) std::this_thread::yield(); }); });
+        std::vector<std::shared_ptr<WorkerPool::Job>> js;
+        for (int i = 0; i < 32; ++i) js.push_back(pool.submit([&]() { jobs_done.fetch_add(1); }));
+        for (auto& j : js) j->wait();
+        if (jobs_done.load() != 32u) { std::printf("jobs: %u of 32 ran\n", jobs_done.load()); return 1; }
+        stop.store(true);
+        busy.join();
     }
     std::atomic<unsigned> after{0};
     pool.run(16, 8, [&](unsigned) { after.fetch_add(1); });

@@ -1,0 +1,89 @@
+"""Round-4 GPU tests: BASELINE config 4 at its own size (1M x 128, 100 000 queries in 8 shards), and what the round added
+to the search path (see the sections below)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity import assert_same  # noqa: E402
+from test_gpu_round2 import _clustered  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------- config 4 at full size
+@pytest.fixture(scope="module")
+def sift1m(native, oracle, tmp_path_factory):
+    """BASELINE config 2 / 4's index at its real size, built once for the module: 1M x 128 clustered, M=16, ef_c=200,
+    GPU-assisted construction (the product's) -> hnswio dump -> product reload and oracle reload of the same files."""
+    tmp = tmp_path_factory.mktemp("sift1m")
+    n, d = 1_000_000, 128
+    X = _clustered(n, d, 0x5EED0001)
+    rng = np.random.default_rng(3)
+    X[rng.choice(n, 2000, replace=False)] = X[rng.choice(n, 2000, replace=False)]  # exact duplicates under distinct ids
+    hb = native.Hnsw(16, n, 16, 200, "DistL2")
+    hb.set_build_options(nthreads=0, gpu_device=0, gpu_window=0)
+    hb.parallel_insert(X)
+    assert hb.get_nb_point() == n
+    hb.file_dump(tmp, "sift1m")
+    del hb
+    h = native.HnswIo(tmp, "sift1m").load_hnsw("DistL2")
+    o = oracle.OracleHnsw.load(tmp, "sift1m", "DistL2")
+    stored = X[np.random.default_rng(4).choice(n, 500, replace=False)].copy()
+    del X
+    return h, o, stored
+
+
+def test_config4_100k_queries_in_8_shards_on_1m_x_128(native, oracle, sift1m):
+    """BASELINE config 4 itself (src/hnsw.rs:1612-1635 fanned out): 100 000 clustered queries against the 1M x 128
+    index, split into 8 contiguous shards of 12 500, searched through hnswgpu_search_batch_sharded_device with one replica per
+    device -- the shards go round-robin over every HIP device of the box (8 real GPUs on an 8-GPU node, eight concurrent
+    shards on device 0 here) -- and every answer (ids, f32 distance bits, p_ids, counts) equals the oracle's.  The same
+    100 000 queries in ONE call on one device give the same answers again."""
+    import torch
+    h, o, stored = sift1m
+    lib = native.lib()
+    k, ef, d, n_sh = 10, 64, 128, 8
+    nq = 100_000
+    Q = _clustered(nq, d, 0x5EED0004)
+    Q[::200] = stored  # 500 queries ARE stored points (distance exactly 0, and the ties of their duplicates)
+    ndev = lib.hnswgpu_device_count()
+    assert ndev >= 1
+    devs = [s % ndev for s in range(n_sh)]
+    sizes = [nq // n_sh] * n_sh
+    bounds = np.cumsum([0] + sizes)
+    tdev = [torch.device("cuda", dv) for dv in devs]
+    qs = [torch.from_numpy(Q[bounds[s]:bounds[s + 1]]).to(tdev[s]) for s in range(n_sh)]
+    ids = [torch.zeros((sizes[s], k), dtype=torch.int64, device=tdev[s]) for s in range(n_sh)]
+    dists = [torch.zeros((sizes[s], k), dtype=torch.float32, device=tdev[s]) for s in range(n_sh)]
+    layers = [torch.zeros((sizes[s], k), dtype=torch.uint8, device=tdev[s]) for s in range(n_sh)]
+    ranks = [torch.zeros((sizes[s], k), dtype=torch.int32, device=tdev[s]) for s in range(n_sh)]
+    counts = [torch.zeros((sizes[s],), dtype=torch.int32, device=tdev[s]) for s in range(n_sh)]
+    streams = [torch.cuda.Stream(tdev[s]) for s in range(n_sh)]
+    for dv in set(devs):
+        torch.cuda.synchronize(dv)
+
+    def ptrs(ts):
+        return (C.c_void_p * n_sh)(*[t.data_ptr() for t in ts])
+
+    rc = lib.hnswgpu_search_batch_sharded_device(h.handle, (C.c_int * n_sh)(*devs), n_sh, ptrs(qs), (C.c_uint64 * n_sh)(*sizes), d, k, ef,
+                                                 ptrs(ids), ptrs(dists), ptrs(layers), ptrs(ranks), ptrs(counts),
+                                                 (C.c_void_p * n_sh)(*[s.cuda_stream for s in streams]))
+    assert rc == 0, native._native.last_error()
+    for dv in set(devs):
+        torch.cuda.synchronize(dv)
+
+    def cat(ts, dtype=None):
+        a = np.concatenate([t.cpu().numpy() for t in ts])
+        return a.astype(dtype) if dtype is not None else a
+
+    got = oracle.SearchResult(cat(ids, np.uint64), cat(dists), cat(layers), cat(ranks), cat(counts, np.uint32))
+    ref = o.parallel_search(Q, k, ef)
+    assert_same(got, ref)
+    print(f"config 4: 100 000 queries in 8 shards over {ndev} device(s) {sorted(set(devs))}: all answers == oracle")
+    # one call, one device, the whole batch (the large-batch end of hnswgpu_search_batch)
+    assert_same(h.parallel_search_flat(Q, k, ef), ref)
+    assert h.last_tie_count() > 0
