@@ -261,6 +261,77 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, nq, cpu_queries, pcts, seed=0xF117):
+    """Row f3 measured like the main row: Hnsw::search_filter with a sorted id vector allowing pct % of the points, nq queries
+    per call with everything resident in HBM (hnswgpu_search_batch_filtered_device): queries/s, the kernel's time (HIP events),
+    per-query work counters -> algorithmic bytes -> fraction of the HBM peak; and, when the oracle is given, its search_filter
+    on the first cpu_queries of the same queries (all host threads): the row's CPU baseline, plus parity of those answers."""
+    import ctypes as C
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Q = synth(nq, d, 0x5EED0002, "clustered")
+    Qd = torch.from_numpy(Q).to(dev)
+    ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    dists = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    layer = torch.zeros((nq, k), dtype=torch.uint8, device=dev)
+    rank = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+    counts = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    stats = torch.zeros((nq, 8), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for pct in pcts:
+        allowed = np.sort(rng.choice(n, max(1, n * pct // 100), replace=False)).astype(np.uint64)  # origin ids = 0..n-1 here
+        ad = torch.from_numpy(allowed.view(np.int64)).to(dev)
+        panics = C.c_uint32(0)
+
+        def call():
+            rc = lib.hnswgpu_search_batch_filtered_device(index.handle, Qd.data_ptr(), nq, d, k, ef, ad.data_ptr(), len(allowed), ids.data_ptr(),
+                                                          dists.data_ptr(), layer.data_ptr(), rank.data_ptr(), counts.data_ptr(),
+                                                          stats.data_ptr(), stream.cuda_stream, C.byref(panics))
+            if rc != 0:
+                raise RuntimeError(H._native.last_error())
+        call()
+        ts, kms = [], []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            call()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+            kms.append(index.last_search_kernel_ms())
+        st = stats.cpu().numpy().astype(np.int64)
+        nd, nx, ni = st[:, 0], st[:, 1], st[:, 2]
+        dur_us = ((st[:, 5] - st[:, 4]) & 0xFFFFFFFF) / 100.0  # 10 ns ticks
+        alg = int(nd.sum()) * d * 4 + int(ni.sum()) * 4 + int(nx.sum()) * 8 + nq * (d * 4 + k * 12)
+        k_ms = float(np.median(kms))
+        e = {"allowed_points": int(len(allowed)), "queries_per_call": nq, "queries_per_s": round(nq / float(np.median(ts)), 1),
+             "kernel": "hnsw_search_exact_kernel", "kernel_ms": round(k_ms, 3),
+             "per_query": {"n_expand_p50_p99_max": [int(np.percentile(nx, 50)), int(np.percentile(nx, 99)), int(nx.max())],
+                           "n_dist_mean": float(nd.mean()), "n_ids_read_mean": float(ni.mean()),
+                           "candidate_heap_entries_left_p50_max": [int(np.percentile(st[:, 6], 50)), int(st[:, 6].max())],
+                           "duration_us_p50_p99_max": [round(float(np.percentile(dur_us, 50)), 1), round(float(np.percentile(dur_us, 99)), 1), round(float(dur_us.max()), 1)],
+                           "us_per_expansion_p50": round(float(np.median(dur_us / np.maximum(nx, 1))), 2)},
+             "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": round(alg / (k_ms * 1e-3) / 1e9, 1),
+             "frac_of_hbm_peak": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "reference_panics": int(panics.value)}
+        if orc is not None and cpu_queries > 0:
+            m = min(nq, cpu_queries)
+            cores = os.cpu_count() or 1
+            best = None
+            for nt in sorted({cores, max(1, cores // 4)}):
+                r = orc.parallel_search_filter(Q[:m], k, ef, allowed, nt)
+                if best is None or r.elapsed_s < best[0]:
+                    best = (r.elapsed_s, nt, r)
+            el, nt, r = best
+            g_ids, g_d, g_c = ids.cpu().numpy().astype(np.uint64)[:m], dists.cpu().numpy()[:m], counts.cpu().numpy().astype(np.uint32)[:m]
+            same = bool(np.array_equal(g_c, r.counts) and all(np.array_equal(g_ids[i, :g_c[i]], r.ids[i, :g_c[i]]) and
+                        np.array_equal(g_d[i, :g_c[i]].view(np.uint32), r.dists[i, :g_c[i]].view(np.uint32)) for i in range(m)))
+            e["cpu_baseline"] = {"value": round(m / el, 1), "unit": "queries/s", "cores": nt, "kind": "port",
+                                 "sample": f"first {m} of the same queries, oracle search_filter on worker threads (one call)"}
+            e["parity_vs_oracle"] = {"queries_checked": m, "ids_distance_bits_counts_identical": same}
+        out[f"{pct}pct"] = e
+    return out
+
+
 def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=5):
     """What a caller pays above the device-buffer call (reported next to `value`, never as `value`):
     * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (H2D + kernels + D2H);

@@ -901,6 +901,8 @@ struct SlabHeader {
 struct FfiAnswer {
     size_t nq, k;
     Vec_api_Neighbourhood* out;
+    Neighbourhood_api* lists;
+    Neighbour_api* rows;
 };
 // A caller that frees its answers (hnswgpu_free_neighbourhood_vec) and asks again gets the same memory back: a 10 000 x 10
 // answer is a 1.9 MB allocation, which malloc serves with mmap / munmap and the kernel with ~470 fresh page faults per call --
@@ -951,41 +953,41 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
     hnswgpu_index* idx = api->idx;
     for (size_t i = 0; i < nb_vec; ++i)
         if (!data[i]) { fail(HNSWGPU_ERR_ARG, "parallel_search_neighbours_f32: null row pointer"); return nullptr; }
-    FfiAnswer ans{nb_vec, knbn, nullptr};
+    FfiAnswer ans{nb_vec, knbn, nullptr, nullptr, nullptr};
     // the row pointers are gathered straight into pinned staging memory (the reference copies them into Vec<Vec<f32>>,
-    // :218-226), the answers are unpacked straight out of it into the slab
-    auto sink = [](void* ctx, const DeviceIndex::HostAnswers& a) {
-        FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
-        const size_t bytes = sizeof(SlabHeader) + sizeof(Vec_api_Neighbourhood) + f.nq * sizeof(Neighbourhood_api) +
-                             f.nq * f.k * sizeof(Neighbour_api);
-        unsigned char* slab = static_cast<unsigned char*>(slab_cache().take(bytes));
-        if (!slab) return;
-        SlabHeader* h = reinterpret_cast<SlabHeader*>(slab);
-        h->magic = SLAB_MAGIC;
-        h->bytes = bytes;
-        Vec_api_Neighbourhood* v = reinterpret_cast<Vec_api_Neighbourhood*>(slab + sizeof(SlabHeader));
-        Neighbourhood_api* lists = reinterpret_cast<Neighbourhood_api*>(v + 1);
-        Neighbour_api* rows = reinterpret_cast<Neighbour_api*>(lists + f.nq);
-        // (a few pool threads: the rows are written once, 16 bytes per neighbour, out of the pinned arena)
-        const unsigned nt = f.nq * f.k < (1u << 14) ? 1u : (unsigned)std::min<size_t>(8, f.nq / 1024 + 1);
-        const size_t per = (f.nq + nt - 1) / nt;
-        WorkerPool::instance().run(nt, nt, [&](unsigned t) {
-            const size_t b = std::min(f.nq, (size_t)t * per), e = std::min(f.nq, ((size_t)t + 1) * per);
-            for (size_t i = b; i < e; ++i) {
+    // :218-226); the slab is taken before the search starts and filled straight out of the pinned answer arena, by the
+    // threads of the call's pool section, range by range
+    DeviceIndex::AnswerSink sink{
+        [](void* ctx, uint64_t nq, uint64_t k) -> bool {
+            FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
+            const size_t bytes = sizeof(SlabHeader) + sizeof(Vec_api_Neighbourhood) + nq * sizeof(Neighbourhood_api) + nq * k * sizeof(Neighbour_api);
+            unsigned char* slab = static_cast<unsigned char*>(slab_cache().take(bytes));
+            if (!slab) return false;
+            SlabHeader* h = reinterpret_cast<SlabHeader*>(slab);
+            h->magic = SLAB_MAGIC;
+            h->bytes = bytes;
+            Vec_api_Neighbourhood* v = reinterpret_cast<Vec_api_Neighbourhood*>(slab + sizeof(SlabHeader));
+            f.lists = reinterpret_cast<Neighbourhood_api*>(v + 1);
+            f.rows = reinterpret_cast<Neighbour_api*>(f.lists + nq);
+            v->len = (int64_t)nq;
+            v->ptr = f.lists;
+            f.out = v;
+            return true;
+        },
+        [](void* ctx, const DeviceIndex::HostAnswers& a, uint64_t lo, uint64_t hi) {
+            FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
+            for (size_t i = lo; i < hi; ++i) {
                 const uint32_t c = a.counts[i];
-                Neighbour_api* r = rows + i * f.k;
+                Neighbour_api* r = f.rows + i * f.k;
                 for (uint32_t j = 0; j < c; ++j) {
                     r[j].id = (size_t)a.ids[i * f.k + j];
                     r[j].d = a.dists[i * f.k + j];
                 }
-                lists[i].nbgh = (int64_t)c;
-                lists[i].neighbours = r;
+                f.lists[i].nbgh = (int64_t)c;
+                f.lists[i].neighbours = r;
             }
-        });
-        v->len = (int64_t)f.nq;
-        v->ptr = lists;
-        f.out = v;
-    };
+        },
+        &ans};
     std::string err;
     int rc;
     {
@@ -995,16 +997,17 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
             std::vector<uint32_t> zero(std::max<size_t>(1, nb_vec), 0u);
             DeviceIndex::HostAnswers a{};
             a.counts = zero.data();
-            sink(&ans, a);
+            if (!sink.begin(&ans, nb_vec, knbn)) { fail(HNSWGPU_ERR_ARG, "out of memory"); return nullptr; }
+            sink.rows(&ans, a, 0, nb_vec);
             return ans.out;
         }
         DeviceIndex* dev = nullptr;
         rc = primary_replica(idx, sl, &dev);
         if (rc != HNSWGPU_OK) return nullptr;
-        rc = dev->search_host_staged(nullptr, data, nb_vec, (uint64_t)vec_len, knbn, ef_search, nullptr, 0, false, false, sink, &ans,
-                                     nullptr, err);
+        rc = dev->search_host_staged(nullptr, data, nb_vec, (uint64_t)vec_len, knbn, ef_search, nullptr, 0, false, false, sink, nullptr, err);
     }
     if (rc != OK) {
+        if (ans.out) hnswgpu_free_neighbourhood_vec(ans.out);  // (taken before the search started)
         fail(rc, err);
         return nullptr;
     }

@@ -360,6 +360,10 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
 }
 
 // Literal search (hnsw_search_exact_kernel) of the queries in d_qlist (nullptr: all nq), optionally filtered.
+// Resident workgroups are what this kernel lives on (a query is one long chain of round trips), so a workgroup gets the LDS
+// that lets the register limit decide (~10 KB: the top ~1 000 entries of the candidate heap) and 1 MB of candidate scratch; a
+// query whose candidate heap outgrows that is listed by the kernel and searched again by a second, narrow launch with room
+// for every point.
 int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_qlist, uint32_t nq, uint64_t k, uint64_t ef,
                            const uint32_t* d_allow, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
                            int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* stats, void* stream_v, uint32_t* panics,
@@ -368,51 +372,70 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
     const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
     const uint32_t bitmap_words = (v_.n + 31) / 32;
     const uint64_t bm_slice = (uint64_t)bitmap_words * sizeof(uint32_t);
-    const uint64_t cand_cap = v_.n;                                   // every point is accepted at most once
-    const uint64_t heap_stride = ef + 2 + cand_cap;
-    const uint64_t per_block = bm_slice + heap_stride * sizeof(hent_t);
-    uint32_t grid = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(1, (8ull << 30) / per_block));
-    grid = std::min<uint32_t>(grid, (uint32_t)num_cu_ * 4u);
-    HIP_TRY(w.bitmap.ensure((uint64_t)grid * bm_slice));
-    HIP_TRY(w.heaps.ensure((uint64_t)grid * heap_stride * sizeof(hent_t)));
-    SearchArgs a{};
-    a.queries = d_qpad;
-    a.qlist = d_qlist;
-    a.nq = nq;
-    a.k = (uint32_t)k;
-    a.ef = (uint32_t)ef;
-    a.tile_bytes = tile_bytes;
-    a.work_counter = static_cast<uint32_t*>(w.d_ctrl);
-    a.overflow_count = static_cast<uint32_t*>(w.d_ctrl) + 1;
-    a.bitmap = w.bitmap.as<uint32_t>();
-    a.bitmap_words = bitmap_words;
-    a.bitmap_blocks = grid;
-    a.nrm2 = static_cast<const double*>(d_nrm2_);
-    a.out_ids = d_out_ids;
-    a.out_dists = d_out_dists;
-    a.out_layer = d_out_layer;
-    a.out_rank = d_out_rank;
-    a.out_counts = d_out_counts;
-    a.stats = stats;
-    a.pre = w.pre.as<PreDescent>();
-    ExactArgs x{};
-    x.heaps = w.heaps.as<hent_t>();
-    x.heap_stride = heap_stride;
-    x.cand_cap = (uint32_t)std::min<uint64_t>(cand_cap, 0xFFFFFFFFull);
-    x.allow = d_allow;
-    // heaps' top levels in LDS: up to ~56 KiB per workgroup (this kernel is latency-, not occupancy-bound)
-    const uint64_t lds_budget = 56 * 1024 - (tile_bytes + IDS_BYTES);
-    x.r_lds_cap = (uint32_t)std::min<uint64_t>(ef + 2, lds_budget / 2 / sizeof(hent_t));
-    x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
-    HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, 16, stream));
-    const size_t lds = tile_bytes + IDS_BYTES + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
     const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
-    HIP_TRY(kernel_set(dist_).launch_exact(ns, grid, lds, stream, v_, a, x));
-    volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);
-    HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 16, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(wait_stream(stream));
-    if (ctrl[1] != 0) { err = "internal error in the literal search kernel (candidate heap overflow or a refused point inside return_points)"; return ERR_DEVICE; }
-    if (panics) *panics = ctrl[2];
+    const KernelSet& ks = kernel_set(dist_);
+    uint32_t panics_total = 0;
+    uint32_t work = nq;
+    const uint32_t* qlist = d_qlist;
+    for (int pass = 0; pass < 2 && work > 0; ++pass) {
+        // pass 0: many workgroups with a bounded candidate heap; pass 1: the queries that outgrew it, every point has room
+        const uint64_t cand_cap = pass == 0 ? std::min<uint64_t>(v_.n, 1ull << 17) : v_.n;
+        const uint64_t heap_stride = ef + 2 + cand_cap;
+        const uint64_t per_block = bm_slice + heap_stride * sizeof(hent_t);
+        ExactArgs x{};
+        // LDS: [query][ids][return_points: ef + 2 entries, or what fits][top of candidate_points]
+        const uint64_t lds_fixed = tile_bytes + IDS_BYTES;
+        const uint64_t lds_budget = std::max<uint64_t>(10 * 1024, lds_fixed + 4096) - lds_fixed;
+        x.r_lds_cap = (uint32_t)std::min<uint64_t>(ef + 2, lds_budget / 2 / sizeof(hent_t));
+        x.cand_lds = (uint32_t)std::min<uint64_t>(cand_cap, (lds_budget - (uint64_t)x.r_lds_cap * sizeof(hent_t)) / sizeof(hent_t));
+        const size_t lds = lds_fixed + ((size_t)x.r_lds_cap + x.cand_lds) * sizeof(hent_t);
+        int per_cu = 0;
+        HIP_TRY(ks.exact_occupancy(ns, lds, &per_cu));
+        per_cu = std::max(1, per_cu);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(work, std::max<uint64_t>(1, (16ull << 30) / per_block));
+        grid = std::min<uint32_t>(grid, (uint32_t)num_cu_ * (uint32_t)per_cu);
+        HIP_TRY(w.bitmap.ensure((uint64_t)grid * bm_slice));
+        HIP_TRY(w.heaps.ensure((uint64_t)grid * heap_stride * sizeof(hent_t)));
+        HIP_TRY(w.retry[0].ensure((uint64_t)nq * sizeof(uint32_t)));
+        if (std::getenv("HNSWGPU_TRACE_LAUNCH"))
+            std::fprintf(stderr, "[hnswgpu launch] literal kernel, pass %d: %u queries on %u workgroups (%d per CU), %zu bytes of LDS each "
+                         "(candidate heap: %u entries in LDS, %llu in all)\n", pass, work, grid, per_cu, lds, x.cand_lds, (unsigned long long)cand_cap);
+        SearchArgs a{};
+        a.queries = d_qpad;
+        a.qlist = qlist;
+        a.nq = work;
+        a.k = (uint32_t)k;
+        a.ef = (uint32_t)ef;
+        a.tile_bytes = tile_bytes;
+        a.work_counter = static_cast<uint32_t*>(w.d_ctrl);
+        a.overflow_count = static_cast<uint32_t*>(w.d_ctrl) + 1;
+        a.retry_out = pass == 0 ? w.retry[0].as<uint32_t>() : nullptr;
+        a.bitmap = w.bitmap.as<uint32_t>();
+        a.bitmap_words = bitmap_words;
+        a.bitmap_blocks = grid;
+        a.nrm2 = static_cast<const double*>(d_nrm2_);
+        a.out_ids = d_out_ids;
+        a.out_dists = d_out_dists;
+        a.out_layer = d_out_layer;
+        a.out_rank = d_out_rank;
+        a.out_counts = d_out_counts;
+        a.stats = stats;
+        a.pre = w.pre.as<PreDescent>();
+        x.heaps = w.heaps.as<hent_t>();
+        x.heap_stride = heap_stride;
+        x.cand_cap = (uint32_t)std::min<uint64_t>(cand_cap, 0xFFFFFFFFull);
+        x.allow = d_allow;
+        HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, 16, stream));
+        HIP_TRY(ks.launch_exact(ns, grid, lds, stream, v_, a, x));
+        volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);
+        HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(wait_stream(stream));
+        if (ctrl[1] != 0) { err = "internal error in the literal search kernel (a refused point inside return_points, or a candidate heap beyond every point)"; return ERR_DEVICE; }
+        panics_total += ctrl[2];
+        work = ctrl[3];
+        qlist = w.retry[0].as<uint32_t>();
+    }
+    if (panics) *panics = panics_total;
     return OK;
 }
 
@@ -468,7 +491,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         }
         // one launch -- or, when the rows are still being gathered into pinned memory, one per chunk: the device reads chunk i
         // across PCIe while the host fills chunk i + 1 (a few chunks: every launch costs a few microseconds of stream time)
-        const uint64_t chunk = feed ? std::max<uint64_t>(1024, (nq + 3) / 4) : nq;
+        const uint64_t chunk = feed ? std::max<uint64_t>(1, feed->chunk_rows) : nq;
         for (uint64_t lo = 0; lo < nq; lo += chunk) {
             const uint64_t hi = std::min(nq, lo + chunk);
             if (feed) feed->fill(feed->ctx, lo, hi);
@@ -701,26 +724,63 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     return OK;
 }
 
-// the staging copies of one call on a few pool threads (a 10 000 x 128 batch is 5 MB in and 1.7 MB out: one core needs
-// ~0.5 ms for it, a third of the search itself); small jobs stay on the calling thread
-template <class F>
-static void parallel_chunks(uint64_t n, uint64_t bytes_per_item, F&& fn) {
-    const uint64_t total = n * bytes_per_item;
-    const unsigned nt = total < (256u << 10) ? 1u : (unsigned)std::min<uint64_t>(8, std::max<uint64_t>(1, total / (128u << 10)));
-    if (nt <= 1 || n < nt) { fn((uint64_t)0, n); return; }
-    const uint64_t per = (n + nt - 1) / nt;
-    WorkerPool::instance().run(nt, nt, [&](unsigned t) {
-        const uint64_t b = std::min<uint64_t>(n, (uint64_t)t * per), e = std::min<uint64_t>(n, ((uint64_t)t + 1) * per);
-        if (b < e) fn(b, e);
-    });
-}
+namespace {
+// What the threads of a host-buffer call share (search_host_staged): gather tasks cut along the chunks the descent kernel is
+// launched on, the hand-over of the answers, unpack tasks.
+struct HostCall {
+    // gather: task t copies rows [t * task_rows, ...) of its chunk; chunk c is complete when chunk_left[c] reaches 0
+    const float* queries;
+    const float* const* rows;
+    float* hq;
+    uint64_t d, nq, chunk_rows, task_rows, tasks_per_chunk, n_chunks;
+    std::atomic<uint64_t> next_gather{0};
+    std::vector<std::atomic<uint32_t>> chunk_left;
+    // answers: 0 = the device is still searching, 2 = ready in the arena, 3 = the call failed
+    std::atomic<int> phase{0};
+    std::atomic<uint64_t> next_unpack{0};
+    uint64_t unpack_rows = 512;
+    DeviceIndex::HostAnswers answers{};
+    const uint32_t* stats = nullptr;   // want_status: [nq][8], status word -> flags[]
+    uint8_t* flags = nullptr;
+    const DeviceIndex::AnswerSink* sink = nullptr;
+    double us_gather = 0., us_unpack = 0.;  // (the caller's share, for HNSWGPU_TRACE_HOST)
+
+    HostCall(uint64_t n_chunks_) : chunk_left(n_chunks_) {}
+    bool gather_one() {  // one task, if any is left
+        const uint64_t t = next_gather.fetch_add(1, std::memory_order_relaxed);
+        if (t >= n_chunks * tasks_per_chunk) return false;
+        const uint64_t c = t / tasks_per_chunk, lo = c * chunk_rows + (t % tasks_per_chunk) * task_rows;
+        const uint64_t hi = std::min({nq, (c + 1) * chunk_rows, lo + task_rows});
+        const uint64_t row_bytes = d * sizeof(float);
+        if (lo < hi) {
+            if (queries) std::memcpy(hq + lo * d, queries + lo * d, (hi - lo) * row_bytes);
+            else for (uint64_t i = lo; i < hi; ++i) std::memcpy(hq + i * d, rows[i], row_bytes);
+        }
+        chunk_left[c].fetch_sub(1, std::memory_order_release);
+        return true;
+    }
+    void unpack_all() {
+        for (;;) {
+            const uint64_t lo = next_unpack.fetch_add(unpack_rows, std::memory_order_relaxed);
+            if (lo >= nq) break;
+            const uint64_t hi = std::min(nq, lo + unpack_rows);
+            if (flags) for (uint64_t i = lo; i < hi; ++i) flags[i] = stats[i * 8 + 3] == 6u ? 1 : 0;
+            sink->rows(sink->ctx, answers, lo, hi);
+        }
+    }
+    static void relax(unsigned& spins) {  // a few ms of busy waiting (the search of a usual batch), then polite polling
+        if (++spins < (1u << 16)) __builtin_ia32_pause();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+};
+}  // namespace
 
 int DeviceIndex::search_host_staged(const float* queries, const float* const* rows, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
-                                    const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, AnswerSink sink,
-                                    void* ctx, CallInfo* info, std::string& err) {
+                                    const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, const AnswerSink& sink,
+                                    CallInfo* info, std::string& err) {
     if (!ready_) { err = "index is not resident on a device: call hnswgpu_upload first"; return ERR_DEVICE; }
     if (nq == 0) { if (info) *info = CallInfo{}; return OK; }
-    if ((!queries && !rows) || !sink) { err = "null buffer"; return ERR_ARG; }
+    if ((!queries && !rows) || !sink.rows) { err = "null buffer"; return ERR_ARG; }
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
     if (k == 0) { err = "knbn must be > 0"; return ERR_ARG; }
     if (filtered && n_allowed && !allowed) { err = "null filter"; return ERR_ARG; }
@@ -731,8 +791,8 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     if (!lease.get()) return ERR_DEVICE;
     Workspace& w = *lease.get();
     hipStream_t stream = w.own_stream;
-    // an error return may leave copies of this call in flight between the staging buffers: they are waited for BEFORE the
-    // workspace goes back to the pool (declared after the lease, destroyed before it)
+    // an error return may leave work of this call in flight on the staging buffers: it is waited for BEFORE the workspace
+    // goes back to the pool (declared after the lease, destroyed before it)
     struct DrainStaging {
         hipStream_t s;
         bool done = false;
@@ -747,6 +807,7 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     auto since = [&](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     };
+    if (sink.begin && !sink.begin(sink.ctx, nq, k)) { err = "out of memory"; return ERR_ARG; }
     const uint64_t q_bytes = nq * d * sizeof(float);
     const uint64_t o_ids = 0, o_dists = o_ids + nq * k * sizeof(uint64_t), o_rank = o_dists + nq * k * sizeof(float),
                    o_layer = o_rank + nq * k * sizeof(int32_t), o_cnt = (o_layer + nq * k + 7) & ~7ull,
@@ -754,7 +815,6 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
                    o_end = o_stat + (want_status ? nq * 8 * sizeof(uint32_t) + nq : 0);
     HIP_TRY(w.pin_in.ensure(q_bytes));
     HIP_TRY(w.pin_out.ensure(o_end));
-    float* hq = static_cast<float*>(w.pin_in.p);
     unsigned char* ho = static_cast<unsigned char*>(w.pin_out.p);
     unsigned char* dout = static_cast<unsigned char*>(w.pin_out.dev);  // the same arena as the device addresses it
     const uint64_t* dallowed = nullptr;
@@ -763,57 +823,78 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         if (n_allowed) HIP_TRY(hipMemcpyAsync(w.allowed_ids.p, allowed, n_allowed * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
         dallowed = w.allowed_ids.as<uint64_t>();
     }
-    // gather (contiguous matrix or row pointers) into pinned memory on a few pool threads, chunk by chunk from inside
-    // search_device: the descent kernel of chunk i reads it across PCIe while chunk i + 1 is gathered
-    struct Feed {
-        const float* queries;
-        const float* const* rows;
-        float* hq;
-        uint64_t d;
-        double us = 0.;
-    } fd{queries, rows, hq, d};
-    RowFeed feed{[](void* ctx, uint64_t lo, uint64_t hi) {
-                     Feed& f = *static_cast<Feed*>(ctx);
-                     const auto t0 = std::chrono::steady_clock::now();
-                     const uint64_t row_bytes = f.d * sizeof(float);
-                     if (f.queries) {
-                         parallel_chunks(hi - lo, row_bytes, [&](uint64_t b, uint64_t e) {
-                             std::memcpy(f.hq + (lo + b) * f.d, f.queries + (lo + b) * f.d, (e - b) * row_bytes);
-                         });
-                     } else {
-                         parallel_chunks(hi - lo, row_bytes, [&](uint64_t b, uint64_t e) {
-                             for (uint64_t i = lo + b; i < lo + e; ++i) std::memcpy(f.hq + i * f.d, f.rows[i], row_bytes);
-                         });
-                     }
-                     f.us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                 },
-                 &fd};
-    const auto t_search = std::chrono::steady_clock::now();
-    int rc = search_device(static_cast<const float*>(w.pin_in.dev), nq, d, k, ef, reinterpret_cast<uint64_t*>(dout + o_ids),
-                           reinterpret_cast<float*>(dout + o_dists), dout + o_layer, reinterpret_cast<int32_t*>(dout + o_rank),
-                           reinterpret_cast<uint32_t*>(dout + o_cnt), want_status ? reinterpret_cast<uint32_t*>(dout + o_stat) : nullptr,
-                           stream, dallowed, filtered ? n_allowed : 0, info, err, &feed);
-    const double us_gather = fd.us;
-    if (rc != OK) return rc;
-    drain.done = true;  // (search_device returns with the stream idle: the answers are in the arena)
-    const double us_search = since(t_search);
-    const auto t_sink = std::chrono::steady_clock::now();
-    HostAnswers a{};
-    a.ids = reinterpret_cast<const uint64_t*>(ho + o_ids);
-    a.dists = reinterpret_cast<const float*>(ho + o_dists);
-    a.rank = reinterpret_cast<const int32_t*>(ho + o_rank);
-    a.layer = ho + o_layer;
-    a.counts = reinterpret_cast<const uint32_t*>(ho + o_cnt);
+    // how many threads, how the work is cut: ~64 KB per gather task, a few chunks (every chunk is a launch of the descent kernel)
+    const uint64_t total_bytes = q_bytes + o_ans_end;
+    const unsigned nt = total_bytes < (256u << 10) ? 1u : (unsigned)std::min<uint64_t>(8, std::max<uint64_t>(2, total_bytes / (256u << 10)));
+    const uint64_t n_chunks = nt == 1 ? 1 : std::min<uint64_t>(4, std::max<uint64_t>(1, nq / 1024));
+    HostCall hc(n_chunks);
+    hc.queries = queries; hc.rows = rows; hc.hq = static_cast<float*>(w.pin_in.p);
+    hc.d = d; hc.nq = nq; hc.n_chunks = n_chunks;
+    hc.chunk_rows = (nq + n_chunks - 1) / n_chunks;
+    hc.task_rows = std::max<uint64_t>(1, std::min<uint64_t>(hc.chunk_rows, (64u << 10) / std::max<uint64_t>(1, d * sizeof(float))));
+    hc.tasks_per_chunk = (hc.chunk_rows + hc.task_rows - 1) / hc.task_rows;
+    for (auto& c : hc.chunk_left) c.store((uint32_t)hc.tasks_per_chunk, std::memory_order_relaxed);
+    hc.sink = &sink;
+    hc.answers.ids = reinterpret_cast<const uint64_t*>(ho + o_ids);
+    hc.answers.dists = reinterpret_cast<const float*>(ho + o_dists);
+    hc.answers.rank = reinterpret_cast<const int32_t*>(ho + o_rank);
+    hc.answers.layer = ho + o_layer;
+    hc.answers.counts = reinterpret_cast<const uint32_t*>(ho + o_cnt);
     if (want_status) {
-        const uint32_t* st = reinterpret_cast<const uint32_t*>(ho + o_stat);
-        uint8_t* flags = ho + o_stat + nq * 8 * sizeof(uint32_t);
-        for (uint64_t i = 0; i < nq; ++i) flags[i] = st[i * 8 + 3] == 6u ? 1 : 0;
-        a.status = flags;
+        hc.stats = reinterpret_cast<const uint32_t*>(ho + o_stat);
+        hc.flags = ho + o_stat + nq * 8 * sizeof(uint32_t);
+        hc.answers.status = hc.flags;
     }
-    sink(ctx, a);
+    // the caller's side of the gather, called from inside search_device in front of every launch of the descent kernel:
+    // rows [lo, hi) -- one chunk -- must be in place; the caller takes gather tasks itself until they are
+    RowFeed feed{[](void* ctx, uint64_t lo, uint64_t) {
+                     HostCall& h = *static_cast<HostCall*>(ctx);
+                     const auto t0 = std::chrono::steady_clock::now();
+                     const uint64_t c = lo / h.chunk_rows;
+                     unsigned spins = 0;
+                     while (h.chunk_left[c].load(std::memory_order_acquire) != 0)
+                         if (!h.gather_one()) HostCall::relax(spins);
+                     h.us_gather += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                 },
+                 &hc, hc.chunk_rows};
+    int rc = OK;
+    double us_search = 0.;
+    const std::thread::id caller = std::this_thread::get_id();
+    std::atomic<bool> main_taken{false};
+    auto participant = [&](unsigned) {
+        if (std::this_thread::get_id() == caller && !main_taken.exchange(true)) {
+            // the caller: the device side of the call (its launches wait for the chunks), then its share of the unpacking
+            const auto t_search = std::chrono::steady_clock::now();
+            rc = search_device(static_cast<const float*>(w.pin_in.dev), nq, d, k, ef, reinterpret_cast<uint64_t*>(dout + o_ids),
+                               reinterpret_cast<float*>(dout + o_dists), dout + o_layer, reinterpret_cast<int32_t*>(dout + o_rank),
+                               reinterpret_cast<uint32_t*>(dout + o_cnt), want_status ? reinterpret_cast<uint32_t*>(dout + o_stat) : nullptr,
+                               stream, dallowed, filtered ? n_allowed : 0, info, err, &feed);
+            us_search = since(t_search);
+            // (search_device returns with the stream idle: the answers are in the arena -- or the call failed, and whatever
+            // it left in flight is waited for by `drain`; the gather is then finished by nobody, which is fine)
+            hc.phase.store(rc == OK ? 2 : 3, std::memory_order_release);
+            if (rc == OK) {
+                const auto t0 = std::chrono::steady_clock::now();
+                hc.unpack_all();
+                hc.us_unpack = since(t0);
+            }
+            return;
+        }
+        // a helper: gather tasks while there are any, stay awake while the device searches, unpack
+        while (hc.phase.load(std::memory_order_relaxed) == 0 && hc.gather_one()) {}
+        unsigned spins = 0;
+        int ph;
+        while ((ph = hc.phase.load(std::memory_order_acquire)) == 0) HostCall::relax(spins);
+        if (ph == 2) hc.unpack_all();
+    };
+    if (nt == 1) participant(0);
+    else WorkerPool::instance().run(nt, nt, participant);
+    if (rc != OK) return rc;
+    drain.done = true;
     if (trace)
-        std::fprintf(stderr, "[hnswgpu host call] %llu queries: %.0f us in all; gather into pinned memory %.0f us (in chunks, inside:) search %.0f us, "
-                     "answers out of the pinned arena %.0f us\n", (unsigned long long)nq, since(t_begin), us_gather, us_search, since(t_sink));
+        std::fprintf(stderr, "[hnswgpu host call] %llu queries on %u threads: %.0f us in all; the caller waited %.0f us for gathered chunks, "
+                     "search %.0f us (descent launches included), its share of the unpacking %.0f us\n",
+                     (unsigned long long)nq, nt, since(t_begin), hc.us_gather, us_search, hc.us_unpack);
     return OK;
 }
 
@@ -823,22 +904,21 @@ int DeviceIndex::search_host(const float* queries, uint64_t nq, uint64_t d, uint
                              CallInfo* info, std::string& err) {
     if (nq != 0 && (!queries || !out_ids || !out_dists || !out_counts)) { err = "null buffer"; return ERR_ARG; }
     struct Out {
-        uint64_t nq, k;
+        uint64_t k;
         uint64_t* ids; float* dists; uint8_t* layer; int32_t* rank; uint32_t* counts; uint8_t* status;
-    } o{nq, k, out_ids, out_dists, out_layer, out_rank, out_counts, out_status};
-    return search_host_staged(queries, nullptr, nq, d, k, ef, allowed, n_allowed, filtered, out_status != nullptr,
-                              [](void* ctx, const HostAnswers& a) {
-                                  Out& o = *static_cast<Out*>(ctx);
-                                  parallel_chunks(o.nq, o.k * 17, [&](uint64_t b, uint64_t e) {
-                                      std::memcpy(o.ids + b * o.k, a.ids + b * o.k, (e - b) * o.k * sizeof(uint64_t));
-                                      std::memcpy(o.dists + b * o.k, a.dists + b * o.k, (e - b) * o.k * sizeof(float));
-                                      if (o.layer) std::memcpy(o.layer + b * o.k, a.layer + b * o.k, (e - b) * o.k);
-                                      if (o.rank) std::memcpy(o.rank + b * o.k, a.rank + b * o.k, (e - b) * o.k * sizeof(int32_t));
-                                      std::memcpy(o.counts + b, a.counts + b, (e - b) * sizeof(uint32_t));
-                                      if (o.status && a.status) std::memcpy(o.status + b, a.status + b, e - b);
-                                  });
-                              },
-                              &o, info, err);
+    } o{k, out_ids, out_dists, out_layer, out_rank, out_counts, out_status};
+    AnswerSink sink{nullptr,
+                    [](void* ctx, const HostAnswers& a, uint64_t b, uint64_t e) {
+                        Out& o = *static_cast<Out*>(ctx);
+                        std::memcpy(o.ids + b * o.k, a.ids + b * o.k, (e - b) * o.k * sizeof(uint64_t));
+                        std::memcpy(o.dists + b * o.k, a.dists + b * o.k, (e - b) * o.k * sizeof(float));
+                        if (o.layer) std::memcpy(o.layer + b * o.k, a.layer + b * o.k, (e - b) * o.k);
+                        if (o.rank) std::memcpy(o.rank + b * o.k, a.rank + b * o.k, (e - b) * o.k * sizeof(int32_t));
+                        std::memcpy(o.counts + b, a.counts + b, (e - b) * sizeof(uint32_t));
+                        if (o.status && a.status) std::memcpy(o.status + b, a.status + b, e - b);
+                    },
+                    &o};
+    return search_host_staged(queries, nullptr, nq, d, k, ef, allowed, n_allowed, filtered, out_status != nullptr, sink, info, err);
 }
 
 

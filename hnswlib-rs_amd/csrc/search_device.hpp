@@ -65,6 +65,7 @@ public:
     struct RowFeed {
         void (*fill)(void* ctx, uint64_t lo, uint64_t hi);
         void* ctx;
+        uint64_t chunk_rows;  // rows per chunk (the feeder's choice: its gather tasks are cut along these)
     };
     int search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                       float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
@@ -76,9 +77,13 @@ public:
                     const uint64_t* allowed, uint64_t n_allowed, bool filtered, uint8_t* out_status, CallInfo* info,
                     std::string& err);
     // What search_host is made of, for callers with other shapes of input / output (the reference's FFI: an array of row
-    // pointers in, per-query vectors out).  Queries come from `queries` (nq x d) or, when that is null, from rows[0..nq);
-    // they are gathered by a few host threads into PINNED staging memory, copied to the device asynchronously, searched, and
-    // the answers come back into pinned memory too; `sink` sees them there (valid only during the call).
+    // pointers in, per-query vectors out).  Queries come from `queries` (nq x d) or, when that is null, from rows[0..nq).
+    // ONE section of the worker pool lasts the whole call: its threads gather the rows into mapped pinned memory (the descent
+    // kernel reads them across PCIe, chunk by chunk, while the next chunk is gathered), stay awake while the device searches,
+    // and unpack the answers the kernels wrote into a pinned arena -- a pool thread takes ~50 us to wake up, which a call of
+    // 1.2 ms cannot afford twice.  sink.begin (may be null) runs before anything else, on the caller's thread (allocate);
+    // sink.rows unpacks the answers of queries [lo, hi) and is called concurrently on disjoint ranges; the HostAnswers are
+    // valid only during the call.
     struct HostAnswers {
         const uint64_t* ids;      // [nq][k]
         const float* dists;       // [nq][k]
@@ -87,9 +92,13 @@ public:
         const uint32_t* counts;   // [nq]
         const uint8_t* status;    // [nq] filtered search: 1 = the reference panics on this query (else nullptr)
     };
-    typedef void (*AnswerSink)(void* ctx, const HostAnswers& a);
+    struct AnswerSink {
+        bool (*begin)(void* ctx, uint64_t nq, uint64_t k);  // false: out of memory
+        void (*rows)(void* ctx, const HostAnswers& a, uint64_t lo, uint64_t hi);
+        void* ctx;
+    };
     int search_host_staged(const float* queries, const float* const* rows, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
-                           const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, AnswerSink sink, void* ctx,
+                           const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, const AnswerSink& sink,
                            CallInfo* info, std::string& err);
 
     // strict ties: decisions that depend on the reference's heap order are resolved with literal heaps

@@ -141,6 +141,7 @@ struct KernelSet {
     hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);
     hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
                                const SearchArgs& a, const ExactArgs& x);
+    hipError_t (*exact_occupancy)(int ns, size_t lds, int* per_cu);
     // first kernel of a call: queries padded, greedy descent of every query (pre[]); then, batch scheduling, the queries in
     // descending order of the descent's distance
     hipError_t (*launch_descend)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const DescendArgs& a);

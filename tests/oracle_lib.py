@@ -76,6 +76,9 @@ def lib():
                                         C.c_void_p]
         L.orc_search_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_parallel_search_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                 C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_heap_retain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_heap_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
@@ -191,6 +194,30 @@ class OracleHnsw:
             raise RuntimeError(_err())
         c = cnt.value
         return ids[:c], dists[:c], layers[:c], ranks[:c]
+
+    def parallel_search_filter(self, queries, k, ef, allowed_ids, nthreads=0, want_counters=False):
+        """search_filter for every row of `queries` on worker threads; .status[i] == 1 where the reference panics."""
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        allowed = np.ascontiguousarray(allowed_ids, dtype=np.uint64)
+        nq, d = queries.shape
+        ids = np.zeros((nq, k), np.uint64)
+        dists = np.zeros((nq, k), np.float32)
+        layers = np.zeros((nq, k), np.uint8)
+        ranks = np.zeros((nq, k), np.int32)
+        counts = np.zeros(nq, np.uint32)
+        status = np.zeros(nq, np.uint8)
+        counters = np.zeros(3, np.uint64)
+        elapsed = C.c_double(0.0)
+        rc = lib().orc_parallel_search_filter(C.c_void_p(self.h), _p(queries), nq, d, k, ef, _p(allowed), len(allowed), nthreads,
+                                              _p(ids), _p(dists), _p(layers), _p(ranks), _p(counts), _p(status),
+                                              _p(counters) if want_counters else None, C.byref(elapsed))
+        if rc != 0:
+            raise RuntimeError(_err())
+        res = SearchResult(ids, dists, layers, ranks, counts)
+        res.status = status
+        res.elapsed_s = elapsed.value
+        res.counters = counters if want_counters else None
+        return res
 
     def flat_baseline(self):
         """The optimised flat-array CPU searcher built from this index (timing only: see oracle/flat_baseline.hpp)."""
