@@ -602,6 +602,16 @@ def main():
         step(0)
         fast_qps = nq_total * args.steps / timed(args.steps)
         lib.hnswgpu_set_strict_ties(index.handle, 1)
+    # for reference: the same steps (strict) with the distances summed in the order of the crate's simdeez_f build -- the
+    # arithmetic of every number the reference publishes, and the fair twin of the CPU baseline's "simd-order" figure
+    # (hnswgpu_set_arithmetic; opt-in, never `value`; its checker is the oracle's dist_simd8: tests/test_gpu_round4.py)
+    simd_qps = None
+    if lib.hnswgpu_set_arithmetic(index.handle, 1) == 0:
+        try:
+            step(0)
+            simd_qps = nq_total * args.steps / timed(args.steps)
+        finally:
+            lib.hnswgpu_set_arithmetic(index.handle, 0)
     # for reference: the same steps issued by two caller threads (each its own stream and output buffers; the library
     # serves concurrent calls from a workspace pool).  One launch ends with its longest search while the machine
     # drains; a second batch in flight fills that tail.  Not `value`: one caller, one batch at a time.
@@ -777,6 +787,7 @@ def main():
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
             "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},
+            "simd_order_queries_per_s": None if simd_qps is None else round(simd_qps, 1),
             "two_caller_threads_queries_per_s": None if two_callers_qps is None else round(two_callers_qps, 1),
             "boundary": boundary,
             "roofline": roofline,

@@ -278,6 +278,10 @@ class Hnsw:
         """Extension: replay tie-affected queries with a literal emulation of the reference's heaps."""
         _check(self._lib.hnswgpu_set_strict_ties(self._h, int(bool(on))))
 
+    def set_arithmetic(self, arithmetic="scalar"):
+        """Extension: "simd8" = distances of the following searches summed in the order of the crate's simdeez_f build."""
+        _check(self._lib.hnswgpu_set_arithmetic(self._h, ARITH[arithmetic]))
+
     def last_tie_count(self):
         n = C.c_uint32()
         _check(self._lib.hnswgpu_last_tie_count(self._h, C.byref(n)))
@@ -371,13 +375,18 @@ def load_description(graph_file_path):
     return d
 
 
-def eval_distance_matrix(dist, queries, rows, batch):
+ARITH = {"scalar": N.HEADER.constants["HNSWGPU_ARITH_SCALAR"], "simd8": N.HEADER.constants["HNSWGPU_ARITH_SIMD8"]}
+
+
+def eval_distance_matrix(dist, queries, rows, batch, arithmetic="scalar"):
     """out[q][r] = Distance<f32>::eval(queries[q], rows[r]) on the device, by the search kernel's own distance routine with
-    the rows taken in batches of `batch` (1..64) -- the lane-group branches the search takes for that many neighbours."""
+    the rows taken in batches of `batch` (1..64) -- the lane-group branches the search takes for that many neighbours.
+    arithmetic: "scalar" (the crate's default build) or "simd8" (the summation order of its simdeez_f build)."""
     q = np.ascontiguousarray(queries, dtype=np.float32)
     r = np.ascontiguousarray(rows, dtype=np.float32)
     out = np.zeros((q.shape[0], r.shape[0]), np.float32)
-    _check(N.lib().hnswgpu_eval_distance_matrix(N.DIST[dist], _p(q), q.shape[0], _p(r), r.shape[0], q.shape[1], batch, _p(out)))
+    _check(N.lib().hnswgpu_eval_distance_matrix_arith(N.DIST[dist], ARITH[arithmetic], _p(q), q.shape[0], _p(r), r.shape[0], q.shape[1],
+                                                      batch, _p(out)))
     return out
 
 

@@ -64,6 +64,7 @@ struct hnswgpu_index {
     int primary = -1;                       // device of the single-GPU entry points
     bool dev_stale = true;
     int strict_ties = -1;  // -1: library default (env HNSWGPU_STRICT_TIES, else on)
+    int arithmetic = 0;    // HNSWGPU_ARITH_*
     BuildParams params;
 
     const FlatIndex* get_flat() {  // exclusive lock held (or the view is known to be fresh)
@@ -102,6 +103,7 @@ static int ensure_device(hnswgpu_index* idx, int device) {
         int rc = dev->upload(*f, device, err);
         if (rc != OK) return fail(rc, err);
         if (idx->strict_ties >= 0) dev->set_strict_ties(idx->strict_ties != 0);
+        dev->set_arithmetic(idx->arithmetic);
         idx->replicas[device] = std::move(dev);
     }
     if (idx->primary < 0 || !idx->replica(idx->primary)) idx->primary = device;
@@ -464,6 +466,7 @@ static int ensure_devices(hnswgpu_index* idx, const int* devices, int n) {
             if (rcs[i] != OK) return fail(rcs[i], "device " + std::to_string(missing[i]) + ": " + errs[i]);
         for (size_t i = 0; i < missing.size(); ++i) {
             if (idx->strict_ties >= 0) fresh[i]->set_strict_ties(idx->strict_ties != 0);
+            fresh[i]->set_arithmetic(idx->arithmetic);
             idx->replicas[missing[i]] = std::move(fresh[i]);
         }
     }
@@ -689,6 +692,14 @@ int hnswgpu_last_search_kernel_ms(const hnswgpu_index* cidx, double* ms) {
     *ms = dev->last_call().main_ms;
     return HNSWGPU_OK;
 }
+int hnswgpu_set_arithmetic(hnswgpu_index* idx, int arithmetic) {
+    if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
+    if (arithmetic != HNSWGPU_ARITH_SCALAR && arithmetic != HNSWGPU_ARITH_SIMD8) return fail(HNSWGPU_ERR_ARG, "unknown arithmetic");
+    std::unique_lock<std::shared_mutex> g(idx->mu);
+    idx->arithmetic = arithmetic;
+    for (auto& kv : idx->replicas) kv.second->set_arithmetic(arithmetic);
+    return HNSWGPU_OK;
+}
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on) {
     if (!idx) return fail(HNSWGPU_ERR_ARG, "null argument");
     std::unique_lock<std::shared_mutex> g(idx->mu);
@@ -721,6 +732,17 @@ int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, co
     if (!queries || !rows || !out || dist < 0 || dist >= DIST_COUNT) return fail(HNSWGPU_ERR_ARG, "bad argument");
     std::string err;
     int rc = eval_distance_matrix_device(dist, queries, nq, rows, n, d, batch, false, out, err);
+    if (rc != OK) return fail(rc, err);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
+int hnswgpu_eval_distance_matrix_arith(int dist, int arithmetic, const float* queries, uint64_t nq, const float* rows, uint64_t n,
+                                       uint64_t d, uint32_t batch, float* out) {
+    CAPI_GUARD_BEGIN
+    if (!queries || !rows || !out || dist < 0 || dist >= DIST_COUNT) return fail(HNSWGPU_ERR_ARG, "bad argument");
+    std::string err;
+    int rc = eval_distance_matrix_device(dist, queries, nq, rows, n, d, batch, false, out, err, arithmetic);
     if (rc != OK) return fail(rc, err);
     return HNSWGPU_OK;
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)

@@ -4,7 +4,8 @@
 //                       PointIndexation: nb_layer, per layer {MAGICLAYER, count, point records
 //                       (:1063-1097, read :1221-1289)}, entry point (:1303-1340)
 //   <base>.hnsw.data  : {MAGICDATAP, dimension} then per point
-//                       {MAGICDATAP, origin_id u64, byte_len u64, raw f32[d]} (:1099-1112, :1382-1383)
+//                       {MAGICDATAP, origin_id u64, byte_len u64, raw f32[d]} (:1099-1112, :1382-1383); format v2 (read only,
+//                       :1157-1158): the payload is bincode's Vec<f32> = u64 count + the elements
 // Native-endian, packed, usize = 8 bytes.  Only DumpMode::Full exists
 // in practice (src/api.rs:81) and only Full can be reloaded (src/hnswio.rs:1237-1243).
 //
@@ -147,7 +148,6 @@ int load_dump(const std::string& dir, const std::string& basename, int asked_dis
     }
     // element type (src/hnswio.rs:629-638: the reference panics)
     if (descr.t_name != "f32") { err = "typename in description (" + descr.t_name + ") is not f32"; return ERR_TYPE; }
-    if (descr.format_version == 2) { err = "dump format v2 (bincode-encoded vectors) is not supported"; return ERR_FORMAT; }
     if (descr.dumpmode != 1) { err = "only DumpMode::Full dumps can be reloaded"; return ERR_FORMAT; }
 
     out = FlatIndex();
@@ -228,6 +228,16 @@ int load_dump(const std::string& dir, const std::string& basename, int asked_dis
             if (dt.get<uint64_t>() != origin) { err = "origin_id incoherent between graph and data"; return ERR_FORMAT; }
             uint64_t slen = dt.get<uint64_t>();
             const uint8_t* raw = dt.bytes(slen);
+            if (descr.format_version == 2) {
+                // v2 dumps (magic 0x002a677f) hold the vector bincode-encoded (src/hnswio.rs:1157-1158: bincode::deserialize of a
+                // Vec<T>; bincode 1 defaults: a u64 little-endian element count, then the elements, little endian)
+                uint64_t cnt = 0;
+                if (!dt.ok || slen < 8) { err = "truncated data file"; return ERR_FORMAT; }
+                std::memcpy(&cnt, raw, 8);
+                if (cnt != d) { err = "bincode-encoded vector (dump format v2) does not have the dimension of the description"; return ERR_FORMAT; }
+                raw += 8;
+                slen -= 8;
+            }
             if (!dt.ok || slen / sizeof(float) < d) { err = "truncated data file"; return ERR_FORMAT; }
             out.origin_id.push_back(origin);
             size_t off = out.vectors.size();

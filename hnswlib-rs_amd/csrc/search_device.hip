@@ -103,6 +103,10 @@ const KernelSet& kernel_set(int metric) {
         case DIST_HELLINGER: return kernels_for<DIST_HELLINGER>();
         case DIST_JEFFREYS: return kernels_for<DIST_JEFFREYS>();
         case DIST_JENSENSHANNON: return kernels_for<DIST_JENSENSHANNON>();
+        case KM_L2_SIMD8: return kernels_for<KM_L2_SIMD8>();
+        case KM_COSINE_SIMD8: return kernels_for<KM_COSINE_SIMD8>();
+        case KM_DOT_SIMD8: return kernels_for<KM_DOT_SIMD8>();
+        case KM_L1_SIMD8: return kernels_for<KM_L1_SIMD8>();
         default: return kernels_for<DIST_L1>();
     }
 }
@@ -248,6 +252,14 @@ void DeviceIndex::release() {
     ready_ = false;
 }
 
+int DeviceIndex::kernel_metric() const {
+    if (arith_.load() == ARITH_SIMD8) {
+        const int km = simd8_kernel_metric(dist_);
+        if (km >= 0) return km;
+    }
+    return dist_;
+}
+
 CallInfo DeviceIndex::last_call() const {
     std::lock_guard<std::mutex> g(meta_mu_);
     return last_;
@@ -369,11 +381,11 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
                            int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* stats, void* stream_v, uint32_t* panics,
                            std::string& err) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
+    const uint32_t tile_bytes = tile_bytes_for(kernel_metric(), v_.row_stride);
     const uint32_t bitmap_words = (v_.n + 31) / 32;
     const uint64_t bm_slice = (uint64_t)bitmap_words * sizeof(uint32_t);
     const int ns = ef <= 64 ? 1 : ef <= 128 ? 2 : 0;  // return_points in VGPRs when it fits (push+pop fused when full)
-    const KernelSet& ks = kernel_set(dist_);
+    const KernelSet& ks = kernel_set(kernel_metric());
     uint32_t panics_total = 0;
     uint32_t work = nq;
     const uint32_t* qlist = d_qlist;
@@ -478,11 +490,11 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     const bool strict_ties = strict_ties_.load();
 
     HIP_TRY(w.pre.ensure(nq * sizeof(PreDescent)));
-    const uint32_t tile_bytes = tile_bytes_for(dist_, v_.row_stride);
+    const uint32_t tile_bytes = tile_bytes_for(kernel_metric(), v_.row_stride);
     HIP_TRY(hipEventRecord(w.ev_start, stream));
     // first kernel of the call: rows padded to the row stride, the greedy descent of every query (pre[]), counters zeroed
     {
-        const KernelSet& ks = kernel_set(dist_);
+        const KernelSet& ks = kernel_set(kernel_metric());
         int per_cu = descend_per_cu_.load();
         if (per_cu <= 0) {
             HIP_TRY(ks.descend_occupancy(tile_bytes + IDS_BYTES, &per_cu));
@@ -566,7 +578,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     const bool scheduled = nq >= 256 && !std::getenv("HNSWGPU_NO_SCHED");
     if (scheduled) {
         HIP_TRY(w.order.ensure(nq * sizeof(uint32_t)));
-        HIP_TRY(kernel_set(dist_).launch_order(stream, w.pre.as<PreDescent>(), (uint32_t)nq, w.order.as<uint32_t>()));
+        HIP_TRY(kernel_set(kernel_metric()).launch_order(stream, w.pre.as<PreDescent>(), (uint32_t)nq, w.order.as<uint32_t>()));
     }
     uint32_t launches = 0, stop_recorded_after = ~0u;
     uint32_t work = (uint32_t)nq;
@@ -593,7 +605,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         a.tile_bytes = tile_bytes;
         a.nrm2 = static_cast<const double*>(d_nrm2_);
         a.idbits = idbits;
-        const KernelSet& ks = kernel_set(dist_);
+        const KernelSet& ks = kernel_set(kernel_metric());
         const bool strict_kernel = strict_ties && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
         if (slots <= (strict_kernel ? HNSW_MERGE_SMAX : HNSW_MERGE_LEAN_SMAX)) {  // merge_list's scatter buffer
             a.merge_entries = (uint32_t)slots * 64u + 64u;
@@ -735,10 +747,13 @@ struct HostCall {
     uint64_t d, nq, chunk_rows, task_rows, tasks_per_chunk, n_chunks;
     std::atomic<uint64_t> next_gather{0};
     std::vector<std::atomic<uint32_t>> chunk_left;
-    // answers: 0 = the device is still searching, 2 = ready in the arena, 3 = the call failed
+    // answers: 0 = the device is still searching, 2 = all of them in the arena, 3 = the call failed; then unpack tasks.
+    // (Unpacking answer by answer WHILE the device searches -- the kernels flagging every finished query in mapped host memory
+    // behind a system-scope fence, the helper threads polling -- was built and measured in round 4: the call went from 1.40 to
+    // 2.03 ms, the fence being an L2 write-back per query.  Removed.)
     std::atomic<int> phase{0};
     std::atomic<uint64_t> next_unpack{0};
-    uint64_t unpack_rows = 512;
+    uint64_t unpack_rows = 256;
     DeviceIndex::HostAnswers answers{};
     const uint32_t* stats = nullptr;   // want_status: [nq][8], status word -> flags[]
     uint8_t* flags = nullptr;
@@ -1168,8 +1183,13 @@ std::unique_ptr<BuildSearchBackend> make_device_build_backend(int device) {
 }
 
 int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
-                                uint32_t nf, bool pairs, float* out, std::string& err) {
+                                uint32_t nf, bool pairs, float* out, std::string& err, int arithmetic) {
     if (nq == 0 || n == 0) return OK;
+    int km = dist;
+    if (arithmetic == ARITH_SIMD8) {
+        km = simd8_kernel_metric(dist);
+        if (km < 0) { err = "this distance has no SIMD-order variant"; return ERR_ARG; }
+    }
     if (!pairs && (nf < 1 || nf > 64)) { err = "nf must be in 1..64"; return ERR_ARG; }
     if (pairs && nq != n) { err = "pair mode needs as many queries as rows"; return ERR_ARG; }
     if (!pairs && nq > 65535) { err = "too many queries for one launch"; return ERR_ARG; }
@@ -1194,12 +1214,12 @@ int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, con
     if (pairs) {
         for (uint64_t q0 = 0; q0 < n; q0 += 32768) {  // gridDim.y is limited to 65535
             const uint32_t cnt = (uint32_t)std::min<uint64_t>(32768, n - q0);
-            HIP_TRY(kernel_set(dist).launch_eval_matrix(nullptr, dq.as<float>() + q0 * rs, cnt, dr.as<float>() + q0 * rs, cnt,
-                                                        dn.p ? dn.as<double>() + q0 : nullptr, dout.as<float>() + q0, rs, 1, true));
+            HIP_TRY(kernel_set(km).launch_eval_matrix(nullptr, dq.as<float>() + q0 * rs, cnt, dr.as<float>() + q0 * rs, cnt,
+                                                      dn.p ? dn.as<double>() + q0 : nullptr, dout.as<float>() + q0, rs, (uint32_t)d, 1, true));
         }
     } else {
-        HIP_TRY(kernel_set(dist).launch_eval_matrix(nullptr, dq.as<float>(), (uint32_t)nq, dr.as<float>(), (uint32_t)n, dn.as<double>(),
-                                                    dout.as<float>(), rs, nf, false));
+        HIP_TRY(kernel_set(km).launch_eval_matrix(nullptr, dq.as<float>(), (uint32_t)nq, dr.as<float>(), (uint32_t)n, dn.as<double>(),
+                                                  dout.as<float>(), rs, (uint32_t)d, nf, false));
     }
     HIP_TRY(hipMemcpy(out, dout.p, n_out * sizeof(float), hipMemcpyDeviceToHost));
     return OK;

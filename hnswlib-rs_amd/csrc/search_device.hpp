@@ -12,6 +12,8 @@
 
 namespace hnswgpu {
 
+constexpr int ARITH_SCALAR = 0, ARITH_SIMD8 = 1;  // DeviceIndex::set_arithmetic
+
 // Plain-pointer view handed to the kernels by value.
 struct DeviceIndexView {
     const float* vec;          // [n][row_stride] f32, rows zero-padded to 128-byte lines
@@ -101,6 +103,11 @@ public:
                            const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, const AnswerSink& sink,
                            CallInfo* info, std::string& err);
 
+    // The arithmetic of Distance::eval: ARITH_SCALAR (default) sums like the crate's default build, left to right, bit for
+    // bit; ARITH_SIMD8 sums DistL2 / DistCosine / DistDot / DistL1 in the order of its simdeez_f / stdsimd builds (8 vertical
+    // accumulators, Cargo.toml:104-111) -- the order behind the reference's published numbers; other distances stay scalar.
+    void set_arithmetic(int a) { arith_.store(a == ARITH_SIMD8 ? ARITH_SIMD8 : ARITH_SCALAR); }
+    int arithmetic() const { return arith_.load(); }
     // strict ties: decisions that depend on the reference's heap order are resolved with literal heaps
     void set_strict_ties(bool on) { strict_ties_.store(on); }
     bool strict_ties() const { return strict_ties_.load(); }
@@ -140,6 +147,8 @@ private:
     uint32_t adapt_tbits_ = 0;
     CallInfo last_{};
     std::atomic<bool> strict_ties_{true};
+    std::atomic<int> arith_{0};
+    int kernel_metric() const;            // dist_, or its SIMD-order kernel variant
     std::atomic<int> descend_per_cu_{0};  // resident workgroups per CU of the descent kernel (asked once)
 };
 
@@ -150,6 +159,6 @@ std::unique_ptr<BuildSearchBackend> make_device_build_backend(int device);
 // rows[r]), rows evaluated in batches of `nf` (1..64) -- the lane-group branches the search takes for nf neighbours.
 // pairs: nq == n and out[i] = dist(queries[i], rows[i]) (nf ignored).
 int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
-                                uint32_t nf, bool pairs, float* out, std::string& err);
+                                uint32_t nf, bool pairs, float* out, std::string& err, int arithmetic = 0);
 
 }  // namespace hnswgpu

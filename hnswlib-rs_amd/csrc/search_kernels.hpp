@@ -14,6 +14,15 @@ constexpr int TABLE_LDS_CELL16 = 0;
 constexpr int TABLE_LDS_CELL32 = 1;
 constexpr int TABLE_GLOBAL_BITMAP = 2;
 
+// kernel "metric" ids beyond the Dist ids of flat_index.hpp: the same distance summed in the crate's simdeez_f order
+// (hnswgpu_set_arithmetic; search_kernels.inc, group_dist_simd8).  Only the search-path kernels exist for them.
+constexpr int KM_SIMD8_FIRST = 7;
+constexpr int KM_L2_SIMD8 = 7, KM_COSINE_SIMD8 = 8, KM_DOT_SIMD8 = 9, KM_L1_SIMD8 = 10;
+constexpr int KM_COUNT = 11;
+inline int simd8_kernel_metric(int dist) {  // -1: the metric has no SIMD-order variant (the probability distances)
+    return dist == DIST_L2 ? KM_L2_SIMD8 : dist == DIST_COSINE ? KM_COSINE_SIMD8 : dist == DIST_DOT ? KM_DOT_SIMD8 : dist == DIST_L1 ? KM_L1_SIMD8 : -1;
+}
+
 constexpr uint32_t IDS_BYTES = 64 * 4;  // LDS: the compacted ids of one batch of neighbours
 
 typedef unsigned long long hent_t;  // heap / log entry: {key f32 (high), id u32 (low)}
@@ -150,7 +159,7 @@ struct KernelSet {
     // arithmetic tests: out[q][r] = dist(queries[q], rows[r]) through batch_dist, rows in batches of nf; or, pairs:
     // out[q] = dist(queries[q], rows[q])
     hipError_t (*launch_eval_matrix)(hipStream_t stream, const float* queries, uint32_t nq, const float* rows, uint32_t n_rows,
-                                     const double* nrm2, float* out, uint32_t row_stride, uint32_t nf, bool pairs);
+                                     const double* nrm2, float* out, uint32_t row_stride, uint32_t d, uint32_t nf, bool pairs);
     // construction: the searches of insert_slice for a window of points (hnsw_build_search_kernel)
     hipError_t (*launch_build_search)(int slots, uint32_t grid, size_t lds, hipStream_t stream, const BuildArgs& a);
     hipError_t (*build_occupancy)(int slots, size_t lds, int* per_cu);
@@ -167,7 +176,7 @@ struct KernelSet {
 #endif
 // LDS in front of the id buffer: the query row; DistCosine keeps the query's squared norm (f64) behind it
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
-    return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE ? 16u : 0u);
+    return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE || metric == KM_COSINE_SIMD8 ? 16u : 0u);
 }
 // kernels_for<METRIC>(): defined in part 2 of that metric's translation units (search_kernels_tu.hip)
 template <int METRIC> const KernelSet& kernels_for();
@@ -178,6 +187,10 @@ template <> const KernelSet& kernels_for<DIST_L1>();
 template <> const KernelSet& kernels_for<DIST_HELLINGER>();
 template <> const KernelSet& kernels_for<DIST_JEFFREYS>();
 template <> const KernelSet& kernels_for<DIST_JENSENSHANNON>();
+template <> const KernelSet& kernels_for<KM_L2_SIMD8>();
+template <> const KernelSet& kernels_for<KM_COSINE_SIMD8>();
+template <> const KernelSet& kernels_for<KM_DOT_SIMD8>();
+template <> const KernelSet& kernels_for<KM_L1_SIMD8>();
 // metric-independent helpers (instantiated once, in part 2 of the L2 units)
 hipError_t launch_allow_bitmap(hipStream_t stream, const uint64_t* origin_id, uint32_t n, const uint64_t* ids, uint64_t m, uint32_t* allow);
 // DistCosine: every point's squared norm (the crate's arithmetic) into out[n] -- or, out == nullptr, into the last 8 bytes of

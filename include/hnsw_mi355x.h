@@ -254,6 +254,20 @@ int hnswgpu_search_batch_end(hnswgpu_ticket* ticket);
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on);
 int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
 
+/* The arithmetic of Distance<f32>::eval during SEARCH (construction always sums like the scalar build).
+ *   HNSWGPU_ARITH_SCALAR (default): the crate's default build -- every sum left to right over the vector index
+ *                                   (anndists 0.1 without features, Cargo.toml:104-106); what the parity tests pin.
+ *   HNSWGPU_ARITH_SIMD8:            the summation order of its `simdeez_f` / `stdsimd` builds (Cargo.toml:107-111; the
+ *                                   builds behind every number the reference publishes, README.md:46-56): 8 vertical f32
+ *                                   accumulators over the full blocks of 8 elements, their horizontal sum, then the d % 8
+ *                                   tail; DistCosine with three such f32 sums.  DistL2 / DistCosine / DistDot / DistL1 only
+ *                                   (other distances keep the scalar order).  Last-bit differences to the scalar build, so
+ *                                   near-tie ids may differ from it; the checker for this mode is the oracle's dist_simd8.
+ * Opt-in, never the default.  Takes effect for the following search calls on every replica of the index.            */
+#define HNSWGPU_ARITH_SCALAR 0
+#define HNSWGPU_ARITH_SIMD8 1
+int hnswgpu_set_arithmetic(hnswgpu_index* idx, int arithmetic);
+
 /* Timing of the kernels of the last search call on this index, measured with HIP events on
  * the launch stream: total milliseconds and number of launches (retries included).        */
 int hnswgpu_last_kernel_ms(const hnswgpu_index* idx, double* ms, uint32_t* launches);
@@ -269,6 +283,9 @@ int hnswgpu_last_search_kernel_ms(const hnswgpu_index* idx, double* ms);
 int hnswgpu_eval_distances(int dist, const float* a, const float* b, uint64_t n, uint64_t d, float* out);
 int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
                                  uint32_t batch, float* out);
+/* the same in the given arithmetic (HNSWGPU_ARITH_*)                                                                  */
+int hnswgpu_eval_distance_matrix_arith(int dist, int arithmetic, const float* queries, uint64_t nq, const float* rows,
+                                       uint64_t n, uint64_t d, uint32_t batch, float* out);
 
 /* =======================================================================================
  * (2) The reference's own C ABI for f32 (src/libext.rs), same names and struct layouts.

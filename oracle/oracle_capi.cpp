@@ -230,6 +230,11 @@ void orc_dist_matrix(int kind, const float* queries, size_t nq, const float* row
     for (size_t q = 0; q < nq; ++q)
         for (size_t r = 0; r < n; ++r) out[q * n + r] = dist_eval((DistKind)kind, queries + q * d, rows + r * d, d);
 }
+// the same matrix in the crate's SIMD summation order (dist_simd8): the checker of the device's opt-in SIMD-order arithmetic
+void orc_dist_matrix_simd8(int kind, const float* queries, size_t nq, const float* rows, size_t n, size_t d, float* out) {
+    for (size_t q = 0; q < nq; ++q)
+        for (size_t r = 0; r < n; ++r) out[q * n + r] = dist_simd8((DistKind)kind, queries + q * d, rows + r * d, d);
+}
 void orc_l2_normalize(float* v, size_t d) { l2_normalize(v, d); }
 // f32::ln restated (ref_logf.hpp) and the host libm's logf, for the exhaustive comparison of the two
 float orc_ref_logf(float x) { return ref_logf(x); }

@@ -12,6 +12,11 @@
 //! arithmetic of anndists included).
 //!
 //! The distance type is chosen from the file name prefix: l2_, l1_, cos_, dot_, hell_, jeff_, js_.
+//!
+//! Two probes localise a mismatch (inputs: tests/golden/make_pin_probes.py): `pin_pairs.bin` -> the crate's `eval` of fixed
+//! vector pairs per distance and dimension (d = 1, 3, 25, 128, 784), and `pin_heap_scripts.bin` -> the pop order and
+//! into_sorted_vec of std's BinaryHeap on tie-heavy scripts.  If the search fixtures differ, these say whether it is the
+//! arithmetic (which distance, which dimension) or the heap order.
 use std::fs;
 use std::io::Write;
 use std::path::Path;
@@ -91,9 +96,115 @@ where
     Ok(())
 }
 
+// ---- probes that LOCALISE a mismatch (tests/golden/make_pin_probes.py wrote the inputs) ------------------------------------
+
+/// `pin_pairs.bin`: blocks {u32 metric, u32 d, u32 n} + n x (a[d], b[d]) f32 -> `pin_pairs.ref.bin`: the same block headers,
+/// each followed by n x u32 = `D::default().eval(a, b).to_bits()`.  Says WHICH distance at WHICH dimension differs.
+fn probe_pairs(dir: &Path) -> anyhow::Result<()> {
+    let path = dir.join("pin_pairs.bin");
+    if !path.exists() {
+        return Ok(());
+    }
+    let b = fs::read(path)?;
+    let mut out = Vec::<u8>::new();
+    let mut off = 0usize;
+    while off + 12 <= b.len() {
+        let (metric, d, n) = (read_u32(&b, off), read_u32(&b, off + 4) as usize, read_u32(&b, off + 8) as usize);
+        off += 12;
+        out.extend_from_slice(&metric.to_le_bytes());
+        out.extend_from_slice(&(d as u32).to_le_bytes());
+        out.extend_from_slice(&(n as u32).to_le_bytes());
+        for _ in 0..n {
+            let rd = |o: usize| -> Vec<f32> { (0..d).map(|j| f32::from_le_bytes([b[o + 4 * j], b[o + 4 * j + 1], b[o + 4 * j + 2], b[o + 4 * j + 3]])).collect() };
+            let (va, vb) = (rd(off), rd(off + 4 * d));
+            off += 8 * d;
+            let v: f32 = match metric {
+                0 => DistL2::default().eval(&va, &vb),
+                1 => DistCosine::default().eval(&va, &vb),
+                2 => DistDot::default().eval(&va, &vb),
+                3 => DistL1::default().eval(&va, &vb),
+                4 => DistHellinger::default().eval(&va, &vb),
+                5 => DistJeffreys::default().eval(&va, &vb),
+                _ => DistJensenShannon::default().eval(&va, &vb),
+            };
+            out.extend_from_slice(&v.to_bits().to_le_bytes());
+        }
+    }
+    fs::File::create(dir.join("pin_pairs.ref.bin"))?.write_all(&out)?;
+    println!("pin_pairs.bin -> pin_pairs.ref.bin");
+    Ok(())
+}
+
+/// An entry ordered by its value ONLY, like `PointWithOrder` (src/hnsw.rs:283-297): the tag shows which of several equal
+/// entries std's heap hands out.
+#[derive(Clone, Copy)]
+struct Tagged(f32, i32);
+impl PartialEq for Tagged {
+    fn eq(&self, o: &Self) -> bool {
+        self.0 == o.0
+    }
+}
+impl Eq for Tagged {}
+impl PartialOrd for Tagged {
+    fn partial_cmp(&self, o: &Self) -> Option<std::cmp::Ordering> {
+        self.0.partial_cmp(&o.0)
+    }
+}
+impl Ord for Tagged {
+    fn cmp(&self, o: &Self) -> std::cmp::Ordering {
+        self.partial_cmp(o).unwrap()
+    }
+}
+
+/// `pin_heap_scripts.bin`: per script {u32 n_ops} + n_ops x {u8 is_pop, f32 value, i32 tag} -> `pin_heap_scripts.ref.bin`:
+/// per script {u32 n_popped, tags..., u32 n_left, tags of into_sorted_vec...}.  Says whether std's BinaryHeap orders equal
+/// entries the way the oracle's restatement does (push / pop / into_sorted_vec).
+fn probe_heaps(dir: &Path) -> anyhow::Result<()> {
+    let path = dir.join("pin_heap_scripts.bin");
+    if !path.exists() {
+        return Ok(());
+    }
+    let b = fs::read(path)?;
+    let mut out = Vec::<u8>::new();
+    let mut off = 0usize;
+    while off + 4 <= b.len() {
+        let n = read_u32(&b, off) as usize;
+        off += 4;
+        let mut heap = std::collections::BinaryHeap::<Tagged>::new();
+        let mut popped = Vec::<i32>::new();
+        for _ in 0..n {
+            let is_pop = b[off] != 0;
+            let val = f32::from_le_bytes([b[off + 1], b[off + 2], b[off + 3], b[off + 4]]);
+            let tag = i32::from_le_bytes([b[off + 5], b[off + 6], b[off + 7], b[off + 8]]);
+            off += 9;
+            if is_pop {
+                if let Some(e) = heap.pop() {
+                    popped.push(e.1);
+                }
+            } else {
+                heap.push(Tagged(val, tag));
+            }
+        }
+        let left = heap.into_sorted_vec();
+        out.extend_from_slice(&(popped.len() as u32).to_le_bytes());
+        for t in &popped {
+            out.extend_from_slice(&t.to_le_bytes());
+        }
+        out.extend_from_slice(&(left.len() as u32).to_le_bytes());
+        for e in &left {
+            out.extend_from_slice(&e.1.to_le_bytes());
+        }
+    }
+    fs::File::create(dir.join("pin_heap_scripts.ref.bin"))?.write_all(&out)?;
+    println!("pin_heap_scripts.bin -> pin_heap_scripts.ref.bin");
+    Ok(())
+}
+
 fn main() -> anyhow::Result<()> {
     let dir = std::env::args().nth(1).unwrap_or_else(|| "tests/golden".to_string());
     let dir = Path::new(&dir);
+    probe_pairs(dir)?;
+    probe_heaps(dir)?;
     let mut names: Vec<String> = fs::read_dir(dir)?
         .filter_map(|e| e.ok())
         .filter_map(|e| e.file_name().to_str().and_then(|s| s.strip_suffix(".queries.bin").map(|s| s.to_string())))

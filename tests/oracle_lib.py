@@ -71,6 +71,7 @@ def lib():
         L.orc_ref_logf_mismatches.restype = C.c_uint64
         L.orc_ref_logf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_dist_matrix.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.orc_dist_matrix_simd8.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_levels.argtypes = [C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_void_p]
         L.orc_heap_exercise.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                         C.c_void_p]
@@ -272,11 +273,13 @@ def dist_eval(kind, a, b):
     return float(lib().orc_dist(DIST_BY_NAME[kind], _p(a), _p(b), a.shape[0]))
 
 
-def dist_matrix(kind, queries, rows):
+def dist_matrix(kind, queries, rows, simd8=False):
+    """out[q][r] = eval(queries[q], rows[r]) in the scalar order, or (simd8) in the crate's SIMD summation order (dist_simd8)."""
     q = np.ascontiguousarray(queries, dtype=np.float32)
     r = np.ascontiguousarray(rows, dtype=np.float32)
     out = np.zeros((q.shape[0], r.shape[0]), np.float32)
-    lib().orc_dist_matrix(DIST_BY_NAME[kind], _p(q), q.shape[0], _p(r), r.shape[0], q.shape[1], _p(out))
+    fn = lib().orc_dist_matrix_simd8 if simd8 else lib().orc_dist_matrix
+    fn(DIST_BY_NAME[kind], _p(q), q.shape[0], _p(r), r.shape[0], q.shape[1], _p(out))
     return out
 
 

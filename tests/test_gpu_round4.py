@@ -87,3 +87,80 @@ def test_config4_100k_queries_in_8_shards_on_1m_x_128(native, oracle, sift1m):
     # one call, one device, the whole batch (the large-batch end of hnswgpu_search_batch)
     assert_same(h.parallel_search_flat(Q, k, ef), ref)
     assert h.last_tie_count() > 0
+
+
+# ------------------------------------------------------------------------------------------------- SIMD-order arithmetic (opt-in)
+SIMD8_DIMS = list(range(1, 131)) + [136, 159, 160, 161, 200, 255, 256, 257, 300, 383, 384, 500, 511, 512, 640, 767, 768, 783, 784, 785, 800]
+
+
+@pytest.mark.parametrize("dist", ["DistL2", "DistL1", "DistDot", "DistCosine"])
+def test_simd8_distance_routine_sweep(native, oracle, dist):
+    """hnswgpu_set_arithmetic(HNSWGPU_ARITH_SIMD8): the search's distance routine in the summation order of the crate's
+    simdeez_f build (Cargo.toml:104-111: 8 vertical f32 accumulators over the full blocks of 8, horizontal sum, d % 8 tail;
+    DistCosine with three such sums) equals the oracle's dist_simd8 BIT FOR BIT for every dimension 1..130 and 21 larger ones
+    (every residue mod 8 and mod 32), rows taken in batches of 1, 31, 32, 33 and 64 (one and two rounds of the 2-lanes-per-row
+    routine).  Tolerance: 0 ulp."""
+    for d in SIMD8_DIMS:
+        rng = np.random.default_rng(1000 + d)
+        X = rng.random((70, d), dtype=np.float32) - np.float32(0.3 if dist != "DistCosine" else 0.0)
+        Q = rng.random((3, d), dtype=np.float32)
+        if dist == "DistDot":
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+            Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+        if dist == "DistCosine" and d > 2:
+            X[3] = 0.0  # the zero-norm rule
+        want = oracle.dist_matrix(dist, Q, X, simd8=True)
+        for batch in ((1, 31, 32, 33, 64) if d in (1, 7, 8, 9, 25, 31, 32, 33, 128, 784) else (33,)):
+            got = native.eval_distance_matrix(dist, Q, X, batch=batch, arithmetic="simd8")
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (dist, d, batch)
+    # and it is a different arithmetic: somewhere the scalar order gives other bits
+    X = np.random.default_rng(5).random((64, 128), dtype=np.float32)
+    Q = np.random.default_rng(6).random((4, 128), dtype=np.float32)
+    if dist == "DistDot":
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if dist != "DistL1":
+        assert not np.array_equal(native.eval_distance_matrix(dist, Q, X, batch=33, arithmetic="simd8").view(np.uint32),
+                                  native.eval_distance_matrix(dist, Q, X, batch=33).view(np.uint32))
+
+
+@pytest.mark.parametrize("dist,d,m,efc,k,ef,normalize", [("DistL2", 128, 16, 200, 10, 64, False), ("DistCosine", 25, 24, 200, 10, 128, False),
+                                                       ("DistDot", 25, 24, 200, 10, 128, True), ("DistL1", 10, 16, 100, 10, 20, False),
+                                                       ("DistL2", 29, 12, 100, 5, 200, False)])
+def test_simd8_search_matches_the_oracle_in_simd_order(native, oracle, tmp_path, dist, d, m, efc, k, ef, normalize):
+    """The whole search in SIMD-order arithmetic == the oracle searching the same dump with its distances in the same order
+    (set_simd_order): ids, distance bits, p_ids, counts; strict ties included.  Switching back restores the scalar answers."""
+    from conftest import normalized, uniform
+    n, nq = 6000, 600
+    X = normalized(n, d, 41) if normalize else uniform(n, d, 41)
+    Q = normalized(nq, d, 42) if normalize else uniform(nq, d, 42)
+    Q[:40] = X[:40]
+    o = oracle.OracleHnsw(m, n, 16, efc, dist)
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "s8")
+    h = native.HnswIo(tmp_path, "s8").load_hnsw(dist)
+    h.upload(0)
+    scalar = o.parallel_search(Q, k, ef)
+    assert_same(h.parallel_search_flat(Q, k, ef), scalar)
+    h.set_arithmetic("simd8")
+    o.set_simd_order(True)
+    assert_same(h.parallel_search_flat(Q, k, ef), o.parallel_search(Q, k, ef))
+    h.set_arithmetic("scalar")
+    o.set_simd_order(False)
+    assert_same(h.parallel_search_flat(Q, k, ef), scalar)
+
+
+def test_simd8_full_size_config2(native, oracle, sift1m):
+    """BASELINE config 2 in the arithmetic of the reference's published numbers: 1M x 128, 10 000 queries, SIMD-order distances
+    on both sides (the device's opt-in mode, the oracle's set_simd_order) -> identical answers."""
+    h, o, stored = sift1m
+    Q = _clustered(10_000, 128, 0x5EED0002)
+    Q[::20] = stored
+    h.upload(0)
+    h.set_arithmetic("simd8")
+    o.set_simd_order(True)
+    try:
+        assert_same(h.parallel_search_flat(Q, 10, 64), o.parallel_search(Q, 10, 64))
+    finally:
+        h.set_arithmetic("scalar")
+        o.set_simd_order(False)

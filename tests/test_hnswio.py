@@ -143,6 +143,52 @@ def test_errors_are_reported_not_fatal(native, oracle, tmp_path):
     assert e.value.code == N.ERR_EMPTY
 
 
+def _as_old_format(gpath, dpath, out_g, out_d, version, d):
+    """A v4 dump rewritten the way the crate's earlier formats read (src/hnswio.rs:956-987, :1155-1166): v3 = v4 without the
+    level scale; v2 additionally holds every vector bincode-encoded (u64 element count + the elements)."""
+    import struct
+    g = open(gpath, "rb").read()
+    magic = {2: 0x002a677f, 3: 0x002a6771}[version]
+    open(out_g, "wb").write(struct.pack("=I", magic) + g[4:6] + g[14:])     # magic | dumpmode, M | (8 bytes of level scale dropped)
+    raw = open(dpath, "rb").read()
+    if version == 3:
+        open(out_d, "wb").write(raw)
+        return
+    out = bytearray(raw[:12])                                              # MAGICDATAP + dimension
+    off, rec = 12, 20 + 4 * d
+    while off < len(raw):
+        out += raw[off:off + 12] + struct.pack("=Q", 8 + 4 * d) + struct.pack("<Q", d) + raw[off + 20:off + rec]
+        off += rec
+    open(out_d, "wb").write(bytes(out))
+
+
+@pytest.mark.parametrize("version", [2, 3])
+def test_earlier_dump_formats_are_read(native, oracle, tmp_path, version):
+    """Dumps of format v3 (no level scale) and v2 (bincode-encoded vectors, magic 0x002a677f: src/hnswio.rs:1157-1158) load into
+    the same index as their v4 twin: same vectors, lists, entry point -- dumping the loaded index gives the v4 files again
+    (but for the level scale a v2 / v3 description does not carry: the reader's default 1.0 stands in, as in the reference)."""
+    d = 5
+    gpath, dpath = _dump(oracle, tmp_path)
+    _as_old_format(gpath, dpath, tmp_path / "old.hnsw.graph", tmp_path / "old.hnsw.data", version, d)
+    h_new = native.HnswIo(tmp_path, "x").load_hnsw("DistL2")
+    h_old = native.HnswIo(tmp_path, "old").load_hnsw("DistL2")
+    assert h_old.get_nb_point() == h_new.get_nb_point() == 200
+    h_new.file_dump(tmp_path, "again_new")
+    h_old.file_dump(tmp_path, "again_old")
+    a, b = open(tmp_path / "again_new.hnsw.graph", "rb").read(), open(tmp_path / "again_old.hnsw.graph", "rb").read()
+    assert a[:6] == b[:6] and a[14:] == b[14:]          # everything but the level scale
+    assert open(tmp_path / "again_new.hnsw.data", "rb").read() == open(tmp_path / "again_old.hnsw.data", "rb").read()
+    # a v2 record whose bincode count is not the dimension is refused, not misread
+    if version == 2:
+        bad = bytearray(open(tmp_path / "old.hnsw.data", "rb").read())
+        bad[12 + 20] ^= 0x01
+        open(tmp_path / "badv2.hnsw.graph", "wb").write(open(tmp_path / "old.hnsw.graph", "rb").read())
+        open(tmp_path / "badv2.hnsw.data", "wb").write(bytes(bad))
+        with pytest.raises(native.HnswError) as e:
+            native.HnswIo(tmp_path, "badv2").load_hnsw("DistL2")
+        assert e.value.code == native._native.ERR_FORMAT
+
+
 def test_unsorted_lists_are_resorted_on_reload(native, oracle, tmp_path):
     """Reload re-sorts every list by stored distance (src/hnswio.rs:731)."""
     gpath, dpath = _dump(oracle, tmp_path, "s")
