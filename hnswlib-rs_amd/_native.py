@@ -15,7 +15,11 @@ LIB_PATH = os.path.join(PKG_DIR, "libhnsw_mi355x.so")
 # tuning hook: load a differently-built variant of the same library (kernel A/B runs in one process tree)
 LIB_OVERRIDE = os.environ.get("HNSW_MI355X_LIB")
 
-HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "hnsw_mi355x.h")
+# the header is looked for next to the package (an installed or relocated copy ships it as package data: build_native()
+# refreshes that copy) and, in the source tree, under ../include -- the tree's copy wins when both exist
+_TREE_HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "hnsw_mi355x.h")
+_PKG_HEADER = os.path.join(PKG_DIR, "hnsw_mi355x.h")
+HEADER_PATH = _TREE_HEADER if os.path.exists(_TREE_HEADER) else _PKG_HEADER
 # The header is the one description of the C ABI; structures, prototypes and codes below are READ FROM IT (._cheader).
 HEADER = _cheader.load(HEADER_PATH)
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_DISTANCE, ERR_TYPE, ERR_DEVICE, ERR_EMPTY, ERR_REF_PANIC = (
@@ -38,7 +42,17 @@ def build_native(force=False, verbose=False):
         return (os.path.exists(LIB_PATH)
                 and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs))
 
+    def ship_header():  # the package's own copy of the header (what a relocated package binds from)
+        if os.path.exists(_TREE_HEADER):
+            try:
+                if not os.path.exists(_PKG_HEADER) or open(_PKG_HEADER, "rb").read() != open(_TREE_HEADER, "rb").read():
+                    with open(_PKG_HEADER, "wb") as f:
+                        f.write(open(_TREE_HEADER, "rb").read())
+            except OSError:
+                pass
+
     if not force and fresh():
+        ship_header()
         return LIB_PATH
     # one process per GPU may get here at the same time (bench.py --gpus N): build under a lock, the others then
     # find the library up to date
@@ -55,6 +69,7 @@ def build_native(force=False, verbose=False):
                     raise RuntimeError("building libhnsw_mi355x.so failed")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
+    ship_header()
     return LIB_PATH
 
 

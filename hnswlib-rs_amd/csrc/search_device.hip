@@ -1007,6 +1007,7 @@ public:
     uint32_t rec_words() const override { return 2u + max_stride_; }
     uint32_t* patch_buffer(uint64_t n_records, std::string& err) override {
         DeviceGuard on_device(device_);
+        if (on_device.status() != hipSuccess) { err = std::string("selecting the build device: ") + hipGetErrorString(on_device.status()); return nullptr; }
         const hipError_t e = upd_host_.ensure(std::max<uint64_t>(1, n_records) * rec_words() * sizeof(uint32_t));
         if (e != hipSuccess) { err = std::string("pinned buffer for the list updates: ") + hipGetErrorString(e); return nullptr; }
         return static_cast<uint32_t*>(upd_host_.p);
@@ -1139,6 +1140,9 @@ public:
             const size_t sel_lds = a.tile_bytes + IDS_BYTES + (size_t)sel_stride * 8u;
             const uint32_t sgrid = (uint32_t)std::min<uint64_t>((uint64_t)num_cu_ * 24u, slots);
             HIP_TRY(ks.launch_build_select(sgrid, sel_lds, nullptr, sa));
+            // (a kernel that faults is reported by the synchronising copies below at the latest; asked here so that the
+            // message names the kernel, and before sel_n is trusted)
+            HIP_TRY(hipStreamSynchronize(nullptr));
             out.sel_ids.resize(slots * sel_stride);
             out.sel_d.resize(slots * sel_stride);
             out.sel_n.resize(slots);
@@ -1150,6 +1154,8 @@ public:
             out.out_n.clear();
             out.selected = true;
             out.sel_stride = sel_stride;
+            for (uint64_t sidx = 0; sidx < slots; ++sidx)  // a selection longer than its slot: never read past it
+                if (out.sel_n[sidx] > sel_stride) { err = "internal error: select_neighbours on the device returned more entries than a slot holds"; return ERR_DEVICE; }
             return OK;
         }
         out.out_ids.resize(slots * ef_c_);

@@ -63,3 +63,20 @@ def test_every_prototype_is_exported_with_the_generated_signature(native):
     assert len(hdr.prototypes["parallel_search_neighbours_f32"][1]) == 6
     assert len(hdr.prototypes["search_neighbours_f32"][1]) == 5
     assert hdr.prototypes["parallel_search_neighbours_f32"][0] == C.POINTER(hdr.structs["Vec_api_Neighbourhood"])
+
+
+def test_every_exported_symbol_has_a_parsed_prototype(native):
+    """The other direction: whatever the library EXPORTS under the ABI's names (hnswgpu_* and the reference's own f32
+    symbols) has a prototype the header parser understood -- a declaration the regex parser skipped silently would show up
+    here as an exported symbol without a binding."""
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    ref_names = {"get_hnswio", "init_hnsw_f32", "new_hnsw_f32", "insert_f32", "parallel_insert_f32", "search_neighbours_f32",
+                 "parallel_search_neighbours_f32", "file_dump_f32", "drop_hnsw_f32", "load_hnsw_description", "init_rust_log"}
+    abi = {s for s in exported if s.startswith("hnswgpu_") or s.startswith("load_hnswdump_f32_") or s in ref_names}
+    assert len(abi) >= 60
+    missing = sorted(abi - set(native._native.SYMBOLS))
+    assert not missing, f"exported without a parsed prototype in include/hnsw_mi355x.h: {missing}"
+    # and the package's own copy of the header (what a relocated package binds from) is the tree's
+    pkg = os.path.join(os.path.dirname(native.LIB_PATH), "hnsw_mi355x.h")
+    assert os.path.exists(pkg) and open(pkg).read() == open(HEADER).read()

@@ -56,6 +56,19 @@ case "$EXP" in
   record)
     R=$1; O=gpurun_out/${R}_record
     mkdir -p $O
+    # where and on what tree the record was taken (profiles/traffic.json and the bench line quote it)
+    python - > $O/PROVENANCE.json <<PY
+import hashlib, json, socket, subprocess, time
+def sh(c):
+    try: return subprocess.run(c, shell=True, capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception: return ""
+h = hashlib.sha256()
+for f in ("hnswlib-rs_amd/csrc/search_kernels.inc", "hnswlib-rs_amd/csrc/search_device.hip", "hnswlib-rs_amd/csrc/search_launchers.inc", "bench.py"):
+    h.update(open(f, "rb").read())
+print(json.dumps({"utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": socket.gethostname(),
+                  "gpu": sh("rocm-smi --showproductname --csv | tail -n +2 | head -1")[:120], "gpu_unique_id": sh("rocm-smi --showuniqueid --csv | tail -n +2 | head -1")[:80],
+                  "rocm": sh("cat /opt/rocm/.info/version"), "source_sha256_16": h.hexdigest()[:16]}))
+PY
     stamp "GPU suite"
     timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
     stamp "bench lines (CPU baseline, recall, parity at full size, boundary timings)"

@@ -9,7 +9,20 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+# provenance of the record the counters come from (tools/gpu_call.sh record writes it on the GPU box; the commit is added here,
+# on the machine that has the history): the bench line quotes it, so that a reader sees how stale the counters are
+prov = {}
+pp = os.path.join(ROOT, "profiles", f"{tag}_PROVENANCE.json")
+if os.path.exists(pp):
+    prov = json.load(open(pp))
+if "commit" not in prov:
+    try:
+        import subprocess
+        prov["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+        prov["commit_note"] = "HEAD when profiles/traffic.json was generated; source_sha256_16 identifies the kernel sources the box ran"
+    except Exception:
+        pass
 out = {}
 for cfg in ("sift1m", "glove25", "glove25_dot", "mnist784"):
     sp = os.path.join(ROOT, "profiles", f"{tag}_{cfg}_rocprofv3_summary.txt")
@@ -38,6 +51,7 @@ for cfg in ("sift1m", "glove25", "glove25_dot", "mnist784"):
     ent["source"] = (f"profiles/{tag}_{cfg}_rocprofv3_summary.txt: FETCH_SIZE (KB) x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM "
                      f"section; cross-check TCC_EA0_RDREQ x 128 B) + WRITE_SIZE (KB) x 1024, separate --pmc passes of `python bench.py "
                      f"--config {cfg} --steps 5 --warmup 1`; fabric-side requests: Infinity-Cache hits are included")
+    ent["provenance"] = dict(prov, round=tag)
     out[cfg] = ent
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for cfg, ent in out.items():
