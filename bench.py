@@ -67,6 +67,13 @@ def synth(n, d, seed, kind):
     return out
 
 
+def spin_up(fn, seconds=0.3):
+    """Untimed: calls fn until `seconds` have passed -- GPU clocks are back up after an idle period (see main)."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+
+
 def ground_truth(torch, Xd, Qd, k, dist):
     """Exact k-NN on the GPU: GEMM shortlist of 4k candidates, then f64 re-evaluation of the metric."""
     nq = Qd.shape[0]
@@ -95,7 +102,7 @@ def ground_truth(torch, Xd, Qd, k, dist):
     return ids, dd
 
 
-def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cnt, cpu_seconds):
+def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cnt, cpu_seconds, orc=None):
     """Times the oracle (CPU restatement of the reference, test infrastructure) on the same graph and queries and
     compares the device answers with it.  Returns (cpu_baseline, parity) for the bench line.
     Protocol: wall time of the whole batched call, 1 warm-up + median of 5, on a sample of the batch sized
@@ -103,9 +110,11 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     import oracle_lib
     nq_local = Q.shape[0]
     cores = os.cpu_count() or 1
-    t0 = time.time()
-    orc = oracle_lib.OracleHnsw.load(cache_dir, base, dist)
-    log(f"oracle reloaded the same dump in {time.time() - t0:.1f} s; timing parallel_search on {cores} threads")
+    if orc is None:
+        t0 = time.time()
+        orc = oracle_lib.OracleHnsw.load(cache_dir, base, dist)
+        log(f"oracle reloaded the same dump in {time.time() - t0:.1f} s")
+    log(f"timing the oracle's parallel_search on {cores} threads")
     probe = min(nq_local, 256)
     r = orc.parallel_search(Q[:probe], k, ef, cores)
     rate = probe / max(r.elapsed_s, 1e-6)
@@ -261,14 +270,15 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, nq, cpu_queries, pcts, seed=0xF117):
-    """Row f3 measured like the main row: Hnsw::search_filter with a sorted id vector allowing pct % of the points, nq queries
-    per call with everything resident in HBM (hnswgpu_search_batch_filtered_device): queries/s, the kernel's time (HIP events),
+def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, cpu_queries, pcts, seed=0xF117):
+    """Row f3 measured like the main row: Hnsw::search_filter with a sorted id vector allowing pct % of the points, the queries
+    Q in one call with everything resident in HBM (hnswgpu_search_batch_filtered_device): queries/s, the kernel's time (HIP events),
     per-query work counters -> algorithmic bytes -> fraction of the HBM peak; and, when the oracle is given, its search_filter
     on the first cpu_queries of the same queries (all host threads): the row's CPU baseline, plus parity of those answers."""
     import ctypes as C
     dev = torch.device("cuda", torch.cuda.current_device())
-    Q = synth(nq, d, 0x5EED0002, "clustered")
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    nq = Q.shape[0]
     Qd = torch.from_numpy(Q).to(dev)
     ids = torch.zeros((nq, k), dtype=torch.int64, device=dev)
     dists = torch.zeros((nq, k), dtype=torch.float32, device=dev)
@@ -290,7 +300,7 @@ def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, nq, cpu_queries, pc
                                                           stats.data_ptr(), stream.cuda_stream, C.byref(panics))
             if rc != 0:
                 raise RuntimeError(H._native.last_error())
-        call()
+        spin_up(call, 0.2)
         ts, kms = [], []
         for _ in range(3):
             torch.cuda.synchronize(dev)
@@ -343,7 +353,7 @@ def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, rep
     out = {}
 
     def rate(fn, nrep=reps):
-        fn()
+        spin_up(fn)  # (this block follows host-only work: see spin_up)
         ts = []
         for _ in range(nrep):
             t0 = time.perf_counter()
@@ -375,20 +385,8 @@ def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, rep
             out["ffi_parallel_search_neighbours_f32_queries_per_s"] = round(rate(ffi_call), 1)
             out["ffi_first_answer_ids"] = first.get("ids0")
             lib.drop_hnsw_f32(api)
-    rng = np.random.default_rng(0xF117)
-    for pct in (1, 30):
-        allowed = np.sort(rng.choice(n, max(1, n * pct // 100), replace=False)).astype(np.uint64)  # origin ids = 0..n-1 here
-        sub = Q[: min(nq, 2000)]
-        t = []
-        index.parallel_search_filter_flat(sub, k, ef, allowed)
-        for _ in range(3):
-            t0 = time.perf_counter()
-            index.parallel_search_filter_flat(sub, k, ef, allowed)
-            t.append(time.perf_counter() - t0)
-        out[f"filtered_{pct}pct_queries_per_s"] = round(sub.shape[0] / float(np.median(t)), 1)
-        out[f"filtered_{pct}pct_kernel_ms"] = round(index.last_kernel_ms()[0], 3)
-    out["filtered_note"] = "2 000 queries per call, host buffers, hnsw_search_exact_kernel (both heaps literal, allow bitmap built per call)"
     return out
+
 
 
 def main():
@@ -524,40 +522,56 @@ def main():
     # the answers of a rank live side by side in ONE byte buffer (ids | distances | counts): the search writes the collective's
     # send buffer in place and the exchange is ONE all-gather per step (hnsw_rs_amd.sharded)
     from hnsw_rs_amd.sharded import AnswerGather, PackedAnswers
-    packed = PackedAnswers(nq_local, k, dev)
+    # N > 1: two such buffers alternate, so that the exchange of step i (its own stream inside RCCL) overlaps the search of
+    # step i + 1; a buffer is rewritten only after its exchange has been waited for, and the timed region ends with every
+    # exchange complete
+    packs = [PackedAnswers(nq_local, k, dev) for _ in range(2 if world > 1 else 1)]
+    packed = packs[0]
     out_ids, out_dists, out_counts = packed.ids, packed.dists, packed.counts
     out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
     out_rank = torch.zeros((nq_local, k), dtype=torch.int32, device=dev)
     stats = torch.zeros((nq_local, 8), dtype=torch.int32, device=dev)
-    gatherer = AnswerGather(nq_total, k, world, coll_dev) if world > 1 else None
+    gatherers = [AnswerGather(nq_total, k, world, coll_dev) for _ in packs] if world > 1 else []
+    gatherer = gatherers[0] if gatherers else None
+    in_flight = [None, None]  # work handle of the exchange that last used packs[b]
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
     main_ms = []
     gather_marks = []  # per step: (event before, event after) the all-gather on the launch stream, or host seconds (gloo)
 
-    def step(i):
-        rc = lib.hnswgpu_search_batch_device(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, out_ids.data_ptr(),
-                                             out_dists.data_ptr(), out_layer.data_ptr(), out_rank.data_ptr(),
-                                             out_counts.data_ptr(), stats.data_ptr(), stream.cuda_stream)
+    def drain_exchanges():
+        for b in range(len(in_flight)):
+            if in_flight[b] is not None:
+                in_flight[b].wait()
+                in_flight[b] = None
+
+    def step(i, overlap=True):
+        b = i % len(packs)
+        pk = packs[b]
+        if in_flight[b] is not None:  # the exchange that last read this buffer (two steps ago)
+            in_flight[b].wait()
+            in_flight[b] = None
+        rc = lib.hnswgpu_search_batch_device(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, pk.ids.data_ptr(),
+                                             pk.dists.data_ptr(), out_layer.data_ptr(), out_rank.data_ptr(),
+                                             pk.counts.data_ptr(), stats.data_ptr(), stream.cuda_stream)
         if rc != 0:
             raise RuntimeError(H._native.last_error())
         ms, _ = index.last_kernel_ms()  # HIP events on the launch stream, inside the library
         kernel_ms.append(ms)
         main_ms.append(index.last_search_kernel_ms())
         if world > 1:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
-            if backend_used == "nccl":
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                gatherer.gather(packed)
-                e1.record(stream)
-                gather_marks.append((e0, e1))
-            else:
-                t0 = time.perf_counter()
-                gatherer.gather(packed)
+            t0 = time.perf_counter()
+            if overlap:
+                in_flight[b] = gatherers[b].gather(pk, async_op=True)
+            else:  # (measured alone: what an exchange costs when nothing hides it)
+                gatherers[b].gather(pk)
+                if backend_used == "nccl":
+                    torch.cuda.synchronize(dev)
                 gather_marks.append(time.perf_counter() - t0)
 
     def fence():
+        drain_exchanges()
         if world > 1:
             dist_pg.barrier()
         torch.cuda.synchronize(dev)
@@ -575,6 +589,10 @@ def main():
             el = float(t.item())
         return el
 
+    # The device idles through the setup above (index load, data generation on the host cores) and its clocks fall back: the
+    # first ~0.1 s of work after an idle period runs several times slower (measured: 27 ms instead of 1.4 ms per call right after
+    # a 5 s pause).  Untimed spin-up until the clocks are back, then the W warm-up steps the contract asks for, then the K timed ones.
+    spin_up(lambda: step(0))
     for i in range(args.warmup):
         step(i)
     kernel_ms.clear()
@@ -586,8 +604,14 @@ def main():
     timed_main_ms = list(main_ms)
     timed_kernel_ms = list(kernel_ms)
     gather_ms = None
-    if world > 1 and gather_marks:  # (the stream is idle: timed() ended with a synchronize)
-        gather_ms = float(np.mean([m[0].elapsed_time(m[1]) if isinstance(m, tuple) else m * 1e3 for m in gather_marks]))
+    if world > 1:  # untimed: a few steps with the exchange NOT overlapped and waited for, to say what one costs by itself
+        gather_marks.clear()
+        for i in range(4):
+            step(i, overlap=False)
+        fence()
+        gather_ms = float(np.median(gather_marks)) * 1e3
+        kernel_ms[:] = kernel_ms[:len(timed_kernel_ms)]
+        main_ms[:] = main_ms[:len(timed_main_ms)]
 
     # untimed accounting: one more step per batch for its work counters (the algorithmic bytes of that batch)
     batch_stats = []
@@ -658,9 +682,22 @@ def main():
             log(f"two-caller measurement skipped: {e}")
             two_callers_qps = None
     boundary = None
+    orc = None  # the oracle: checker and CPU baseline (rank 0, N = 1 only), never on the product path
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib
+        t0 = time.time()
+        orc = oracle_lib.OracleHnsw.load(args.cache_dir, base, cfg["dist"])
+        log(f"oracle reloaded the same dump in {time.time() - t0:.1f} s")
     if world == 1 and not args.no_boundary:
         try:  # informational figures: never at the expense of the line itself
             boundary = boundary_timings(H, lib, index, args.cache_dir, base, cfg["dist"], Q, k, ef, n)
+            # row f3, measured like the main row: counters -> algorithmic bytes -> fraction of the peak, the oracle's
+            # search_filter beside it, parity of its sample; at 2 000 queries per call (what rounds 2-3 reported) and at the
+            # main row's batch size
+            boundary["filtered"] = {"note": "Hnsw::search_filter with a sorted id vector allowing 1 % / 30 % of the points, device-resident buffers "
+                                            "(hnswgpu_search_batch_filtered_device), allow bitmap built per call, hnsw_search_exact_kernel",
+                                    "2000_queries_per_call": filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q[:2000], 128, [1, 30]),
+                                    "%d_queries_per_call" % len(Q): filtered_measure(torch, H, lib, index, None, n, d, k, ef, Q, 0, [1, 30])}
         except Exception as e:  # noqa: BLE001
             log(f"boundary timings skipped: {e}")
     step(0)   # leave the strict answers of batch 0 in the output buffers for the recall / parity checks below
@@ -768,7 +805,7 @@ def main():
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_baseline_leg(args.cache_dir, base, cfg["dist"], Q, k, ef, res_ids, out_dists.cpu().numpy(),
-                                                st, cnt, args.cpu_seconds)
+                                                st, cnt, args.cpu_seconds, orc)
 
     if rank == 0:
         out = {
@@ -779,8 +816,9 @@ def main():
             "config": {"workload": cfg["label"], "n": n, "d": d, "distance": cfg["dist"], "M": cfg["M"],
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
                        "queries_total": nq_total, "graph": "replicated per GPU",
-                       "exchange": ("one all_gather_into_tensor per step of the packed answers (ids | distances | counts, %d bytes per rank) over %s"
-                                    % (gatherer.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
+                       "exchange": ("one all_gather_into_tensor per step of the packed answers (ids | distances | counts, %d bytes per rank) over %s, "
+                                    "issued asynchronously: it overlaps the search of the next step (two answer buffers alternate); the timed "
+                                    "region ends with every exchange complete" % (gatherer.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
                        "parallelism": f"{world} x (replica + {nq_local} queries)"},
             "rccl": rccl,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),

@@ -58,14 +58,17 @@ class AnswerGather:
         self.coll_device = torch.device(coll_device)
         self.recv = torch.empty(self.world * self.shard_bytes, dtype=torch.uint8, device=self.coll_device)
 
-    def gather(self, packed):
-        """packed: this rank's PackedAnswers with `rows` == max_shard_rows (shorter shards leave the tail unused)."""
+    def gather(self, packed, async_op=False):
+        """packed: this rank's PackedAnswers with `rows` == max_shard_rows (shorter shards leave the tail unused).
+        async_op: returns the collective's work handle at once (wait() on it before `recv` is read or `packed` rewritten):
+        the exchange of one batch then overlaps the search of the next (two PackedAnswers / AnswerGather pairs, alternating)."""
         import torch.distributed as dist
         if packed.rows != self.rows or packed.k != self.k:
             raise ValueError("PackedAnswers of %d x %d rows, the gather was sized for %d x %d" % (packed.rows, packed.k, self.rows, self.k))
         send = packed.buf if packed.buf.device == self.coll_device else packed.buf.to(self.coll_device)
-        dist.all_gather_into_tensor(self.recv, send, group=self.group)
-        return self.recv
+        self._send = send  # (kept alive until the collective is done)
+        work = dist.all_gather_into_tensor(self.recv, send, group=self.group, async_op=async_op)
+        return work if async_op else self.recv
 
     def in_input_order(self):
         """(ids [nq,k], dists [nq,k], counts [nq]) of the last gather, shards put back side by side."""

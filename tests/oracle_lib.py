@@ -115,8 +115,11 @@ class OracleHnsw:
                 raise RuntimeError(_err())
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:  # (module globals may be gone at interpreter shutdown)
+            try:
+                _lib.orc_free(self.h)
+            except Exception:  # noqa: BLE001
+                pass
             self.h = None
 
     def modify_level_scale(self, f):

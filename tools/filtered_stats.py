@@ -39,5 +39,8 @@ index.upload(0)
 lib = H.lib()
 orc = oracle_lib.OracleHnsw.load(args.cache_dir, base, cfg["dist"])
 n, d, k, ef = cfg["n"], cfg["d"], cfg["k"], cfg["ef"]
-out = bench.filtered_measure(torch, H, lib, index, orc, n, d, k, ef, args.nq, args.cpu_queries, [int(p) for p in args.pcts.split(",")])
+Q = bench.synth(args.nq, d, 0x5EED0002, "clustered")
+if cfg["dist"] == "DistDot":
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+out = bench.filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, args.cpu_queries, [int(p) for p in args.pcts.split(",")])
 print(json.dumps(out, indent=1))

@@ -17,14 +17,14 @@ HIPFLAGS="--offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt"
 if [ -n "${ONLY_METRICS:-}" ]; then
   flock .build.lock make -j8 >/dev/null   # the product's objects, up to date (one make at a time)
   for f in hnswio builder datamap capi search_device; do cp $f.o $OBJ/$f.o; done
-  for m in 0 1 2 3 4 5 6; do for p in 0 1 2; do cp sk_${m}_$p.o $OBJ/sk_${m}_$p.o; done; done
+  for m in 0 1 2 3 4 5 6 7 8 9 10; do for p in 0 1 2; do cp sk_${m}_$p.o $OBJ/sk_${m}_$p.o; done; done
   METRICS="$ONLY_METRICS"
 else
   for m in hnswio builder datamap capi; do
     g++ $CXXFLAGS $2 -c $m.cpp -o $OBJ/$m.o &
   done
   /opt/rocm/bin/hipcc $CXXFLAGS $HIPFLAGS $2 -c search_device.hip -o $OBJ/search_device.o &
-  METRICS="0 1 2 3 4 5 6"
+  METRICS="0 1 2 3 4 5 6 7 8 9 10"
 fi
 for m in $METRICS; do
   for p in 0 1 2; do
@@ -34,7 +34,7 @@ for m in $METRICS; do
 done
 wait
 KOBJS=""
-for m in 0 1 2 3 4 5 6; do for p in 0 1 2; do KOBJS="$KOBJS $OBJ/sk_${m}_$p.o"; done; done
+for m in 0 1 2 3 4 5 6 7 8 9 10; do for p in 0 1 2; do KOBJS="$KOBJS $OBJ/sk_${m}_$p.o"; done; done
 /opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 -o ../lib_$1.so $OBJ/hnswio.o $OBJ/builder.o $OBJ/datamap.o $OBJ/capi.o \
     $OBJ/search_device.o $KOBJS -Wl,-rpath,/opt/rocm/lib
 ls -la ../lib_$1.so
