@@ -546,7 +546,7 @@ def main():
                 in_flight[b].wait()
                 in_flight[b] = None
 
-    def step(i, overlap=True):
+    def step(i, overlap=True, exchange=True):
         b = i % len(packs)
         pk = packs[b]
         if in_flight[b] is not None:  # the exchange that last read this buffer (two steps ago)
@@ -560,7 +560,7 @@ def main():
         ms, _ = index.last_kernel_ms()  # HIP events on the launch stream, inside the library
         kernel_ms.append(ms)
         main_ms.append(index.last_search_kernel_ms())
-        if world > 1:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
+        if world > 1 and exchange:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
             t0 = time.perf_counter()
             if overlap:
                 in_flight[b] = gatherers[b].gather(pk, async_op=True)
@@ -592,7 +592,13 @@ def main():
     # The device idles through the setup above (index load, data generation on the host cores) and its clocks fall back: the
     # first ~0.1 s of work after an idle period runs several times slower (measured: 27 ms instead of 1.4 ms per call right after
     # a 5 s pause).  Untimed spin-up until the clocks are back, then the W warm-up steps the contract asks for, then the K timed ones.
-    spin_up(lambda: step(0))
+    # (no exchange in there: the ranks spin by the clock, not by a common count, and collectives must pair up)
+    _spin = [0]
+
+    def _spin_step():  # (the batches rotate here too: a profiler's per-kernel average is then over all of them)
+        step(_spin[0], exchange=False)
+        _spin[0] += 1
+    spin_up(_spin_step)
     for i in range(args.warmup):
         step(i)
     kernel_ms.clear()
