@@ -520,20 +520,17 @@ def main():
     Qds = [torch.from_numpy(q).to(dev) for q in Qh]
     Qd = Qds[0]
     # the answers of a rank live side by side in ONE byte buffer (ids | distances | counts): the search writes the collective's
-    # send buffer in place and the exchange is ONE all-gather per step (hnsw_rs_amd.sharded)
-    from hnsw_rs_amd.sharded import AnswerGather, PackedAnswers
-    # N > 1: two such buffers alternate, so that the exchange of step i (its own stream inside RCCL) overlaps the search of
-    # step i + 1; a buffer is rewritten only after its exchange has been waited for, and the timed region ends with every
-    # exchange complete
-    packs = [PackedAnswers(nq_local, k, dev) for _ in range(2 if world > 1 else 1)]
-    packed = packs[0]
+    # send buffer in place and the exchange is ONE all-gather per step.  N > 1: two such buffers alternate, so that the exchange
+    # of step i (its own stream inside RCCL) overlaps the search of step i + 1; a buffer is rewritten only after its exchange
+    # has been waited for, and the timed region ends with every exchange complete (hnsw_rs_amd.sharded.OverlappedExchange;
+    # CPU-tested over gloo in tests/test_sharding.py)
+    from hnsw_rs_amd.sharded import OverlappedExchange, PackedAnswers
+    xch = OverlappedExchange(nq_total, k, world, dev, coll_dev) if world > 1 else None
+    packed = xch.packs[0] if xch else PackedAnswers(nq_local, k, dev)
     out_ids, out_dists, out_counts = packed.ids, packed.dists, packed.counts
     out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
     out_rank = torch.zeros((nq_local, k), dtype=torch.int32, device=dev)
     stats = torch.zeros((nq_local, 8), dtype=torch.int32, device=dev)
-    gatherers = [AnswerGather(nq_total, k, world, coll_dev) for _ in packs] if world > 1 else []
-    gatherer = gatherers[0] if gatherers else None
-    in_flight = [None, None]  # work handle of the exchange that last used packs[b]
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
@@ -541,17 +538,11 @@ def main():
     gather_marks = []  # per step: (event before, event after) the all-gather on the launch stream, or host seconds (gloo)
 
     def drain_exchanges():
-        for b in range(len(in_flight)):
-            if in_flight[b] is not None:
-                in_flight[b].wait()
-                in_flight[b] = None
+        if xch:
+            xch.drain()
 
     def step(i, overlap=True, exchange=True):
-        b = i % len(packs)
-        pk = packs[b]
-        if in_flight[b] is not None:  # the exchange that last read this buffer (two steps ago)
-            in_flight[b].wait()
-            in_flight[b] = None
+        pk = xch.buffer(i) if xch else packed  # (N > 1: waits for the exchange that last read this buffer, two steps ago)
         rc = lib.hnswgpu_search_batch_device(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, pk.ids.data_ptr(),
                                              pk.dists.data_ptr(), out_layer.data_ptr(), out_rank.data_ptr(),
                                              pk.counts.data_ptr(), stats.data_ptr(), stream.cuda_stream)
@@ -562,10 +553,8 @@ def main():
         main_ms.append(index.last_search_kernel_ms())
         if world > 1 and exchange:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
             t0 = time.perf_counter()
-            if overlap:
-                in_flight[b] = gatherers[b].gather(pk, async_op=True)
-            else:  # (measured alone: what an exchange costs when nothing hides it)
-                gatherers[b].gather(pk)
+            xch.exchange(i, overlap)
+            if not overlap:  # (measured alone: what an exchange costs when nothing hides it)
                 if backend_used == "nccl":
                     torch.cuda.synchronize(dev)
                 gather_marks.append(time.perf_counter() - t0)
@@ -710,7 +699,7 @@ def main():
     fence()
     if args.dump_answers and rank == 0:  # batch 0 in input order: what the caller of parallel_search gets back
         if world > 1:
-            g_ids, g_dists, g_counts = gatherer.in_input_order()
+            g_ids, g_dists, g_counts = xch.gathered(0)
             np.savez(args.dump_answers, ids=g_ids.cpu().numpy(), dists=g_dists.cpu().numpy(), counts=g_counts.cpu().numpy())
         else:
             np.savez(args.dump_answers, ids=out_ids.cpu().numpy(), dists=out_dists.cpu().numpy(), counts=out_counts.cpu().numpy())
@@ -824,7 +813,7 @@ def main():
                        "queries_total": nq_total, "graph": "replicated per GPU",
                        "exchange": ("one all_gather_into_tensor per step of the packed answers (ids | distances | counts, %d bytes per rank) over %s, "
                                     "issued asynchronously: it overlaps the search of the next step (two answer buffers alternate); the timed "
-                                    "region ends with every exchange complete" % (gatherer.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
+                                    "region ends with every exchange complete" % (xch.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
                        "parallelism": f"{world} x (replica + {nq_local} queries)"},
             "rccl": rccl,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),

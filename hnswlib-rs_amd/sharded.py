@@ -82,6 +82,48 @@ class AnswerGather:
         return tuple(torch.cat(p, dim=0) for p in parts)
 
 
+class OverlappedExchange:
+    """The N > 1 exchange of a stream of batches: two PackedAnswers / AnswerGather pairs alternate, so that the all-gather of
+    batch i (asynchronous) overlaps the search of batch i + 1.  Per batch: `pk = buffer(i)` (waits for the exchange that last read
+    that buffer, two batches ago) -> the search writes pk.ids / pk.dists / pk.counts -> `exchange(i)`.  `drain()` waits for
+    everything in flight; `gathered(i)` = the answers of batch i in input order (valid until batch i + 2 is exchanged).
+    Every rank must call exchange() the same number of times in the same order: collectives pair up by order, not by content."""
+
+    def __init__(self, nq_total, k, world_size, device, coll_device, group=None, depth=2):
+        self.rows = max_shard_rows(nq_total, world_size)
+        self.packs = [PackedAnswers(self.rows, k, device) for _ in range(depth)]
+        self.gatherers = [AnswerGather(nq_total, k, world_size, coll_device, group) for _ in range(depth)]
+        self.in_flight = [None] * depth
+
+    def buffer(self, i):
+        b = i % len(self.packs)
+        if self.in_flight[b] is not None:
+            self.in_flight[b].wait()
+            self.in_flight[b] = None
+        return self.packs[b]
+
+    def exchange(self, i, overlap=True):
+        b = i % len(self.packs)
+        if overlap:
+            self.in_flight[b] = self.gatherers[b].gather(self.packs[b], async_op=True)
+        else:
+            self.gatherers[b].gather(self.packs[b])
+
+    def drain(self):
+        for b in range(len(self.in_flight)):
+            if self.in_flight[b] is not None:
+                self.in_flight[b].wait()
+                self.in_flight[b] = None
+
+    def gathered(self, i):
+        self.drain()
+        return self.gatherers[i % len(self.packs)].in_input_order()
+
+    @property
+    def shard_bytes(self):
+        return self.gatherers[0].shard_bytes
+
+
 def gather_answers(local_ids, local_dists, local_counts, nq, group=None):
     """All-gather the per-shard answers into input order (one collective).  Arrays are torch tensors on the group's
     device (shape [nq_local, k] / [nq_local]); shards may differ in length by one row."""

@@ -75,3 +75,71 @@ def test_bench_gpus_n_is_a_plain_command():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, r.stdout + r.stderr
     assert "HIP device" in r.stderr and not r.stdout.strip()
+
+
+WORKER_OVERLAP = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    import hnsw_rs_amd
+    from hnsw_rs_amd.sharded import OverlappedExchange, shard_bounds
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nq_local, k = 37, 5
+    nq = nq_local * world
+    x = OverlappedExchange(nq, k, world, "cpu", "cpu")
+
+    def fill(pk, step, r):          # what "the search" of rank r leaves for batch `step`
+        base = 1000 * step + 100 * r
+        pk.ids[:] = torch.arange(nq_local * k, dtype=torch.int64).view(nq_local, k) + base
+        pk.dists[:] = float(base)
+        pk.counts[:] = step + r
+
+    def expect(step):
+        ids = torch.cat([torch.arange(nq_local * k, dtype=torch.int64).view(nq_local, k) + 1000 * step + 100 * r for r in range(world)])
+        counts = torch.cat([torch.full((nq_local,), step + r, dtype=torch.int32) for r in range(world)])
+        return ids, counts
+
+    ok = True
+    # like bench.py: ranks first spin by the CLOCK without exchanging (different iteration counts per rank), then a common
+    # number of steps with the exchange overlapped; a buffer is reused two steps later, after its exchange was waited for
+    t0 = time.perf_counter(); spins = 0
+    while time.perf_counter() - t0 < 0.05 * (1 + rank):
+        fill(x.buffer(spins), 999, rank); spins += 1
+    for step in range(9):
+        pk = x.buffer(step)
+        if step >= 2:                # the exchange of step - 2 used this pair: it is complete now, and its result intact
+            ids, dd, counts = x.gatherers[step % 2].in_input_order()
+            e_ids, e_counts = expect(step - 2)
+            ok = ok and torch.equal(ids, e_ids) and torch.equal(counts, e_counts) and float(dd[0, 0]) == 1000.0 * (step - 2)
+        fill(pk, step, rank)
+        x.exchange(step, overlap=(step != 4))   # one of them not overlapped, as bench.py's gather_ms steps do
+    ids, dd, counts = x.gathered(8)
+    e_ids, e_counts = expect(8)
+    ok = ok and torch.equal(ids, e_ids) and torch.equal(counts, e_counts)
+    ids, _, _ = x.gathered(7)
+    ok = ok and torch.equal(ids, expect(7)[0])
+    t = torch.ones(1); dist.all_reduce(t)      # collectives still pair up afterwards
+    ok = ok and int(t.item()) == world
+    print("RANK", rank, "spins", spins, "OK" if ok else "MISMATCH", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+""")
+
+
+def test_overlapped_exchange_two_ranks_gloo(tmp_path):
+    """hnsw_rs_amd.sharded.OverlappedExchange, the exchange bench.py --gpus N runs: two packed buffers alternate, the all-gather of
+    batch i is asynchronous and overlaps batch i + 1, a buffer is rewritten only after its exchange completed; ranks that first
+    spin by the clock WITHOUT exchanging (different counts per rank) stay paired afterwards -- the round-4 hang of the N = 2
+    command was a clock-based warm-up that issued collectives."""
+    script = tmp_path / "worker_overlap.py"
+    script.write_text(WORKER_OVERLAP.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK") == 2
