@@ -4,8 +4,9 @@
 // Reference path (file:line under /root/reference):
 //   Hnsw::parallel_search          src/hnsw.rs:1612-1635   -> one wavefront per query, persistent grid; batches of
 //                                                             >= 256 queries are searched longest-first
-//                                                             (hnsw_estimate_kernel + order_desc_kernel)
-//   Hnsw::search_filter(None)      src/hnsw.rs:1487-1580   -> descent prologue + result epilogue
+//                                                             (order_desc_kernel on the descent's distances)
+//   Hnsw::search_filter(None)      src/hnsw.rs:1487-1580   -> hnsw_descend_kernel (padding + greedy descent of every
+//                                                             query, first kernel of a call) + result epilogue
 //   Hnsw::search_layer             src/hnsw.rs:922-1064    -> expansion loop (visited set in LDS, ef-bounded
 //                                                             result/candidate set in VGPRs; literal BinaryHeaps
 //                                                             where equal f32 distances make the reference's
