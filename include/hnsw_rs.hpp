@@ -92,6 +92,8 @@ public:
     // replication into the HBM of one device (one process per GPU)
     void upload(int device = 0) { check(hnswgpu_upload(idx_, device)); }
     void set_strict_ties(bool on) { check(hnswgpu_set_strict_ties(idx_, on)); }
+    // distances of the following searches summed like the crate's simdeez_f build (true) or its default build (false)
+    void set_simd_order_arithmetic(bool on) { check(hnswgpu_set_arithmetic(idx_, on ? HNSWGPU_ARITH_SIMD8 : HNSWGPU_ARITH_SCALAR)); }
 
     // search(&[T], knbn, ef) -> Vec<Neighbour>
     std::vector<Neighbour> search(const std::vector<float>& data, size_t knbn, size_t ef) const {

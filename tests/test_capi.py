@@ -103,6 +103,25 @@ def test_search_without_a_gpu_fails_loudly(native, tmp_path):
         h.upload(0)
 
 
+def test_arithmetic_switch_is_validated_without_a_device(native):
+    """hnswgpu_set_arithmetic: the two documented modes are accepted on any handle (the setting travels to the replicas made
+    later), anything else is refused; the SIMD-order evaluation itself needs the device and says so."""
+    h = native.Hnsw(8, 100, 16, 20, "DistL2")
+    h.insert_serial(uniform(100, 4, 1))
+    h.set_arithmetic("simd8")
+    h.set_arithmetic("scalar")
+    lib, N = native.lib(), native._native
+    assert lib.hnswgpu_set_arithmetic(h.handle, 7) == N.ERR_ARG
+    assert lib.hnswgpu_set_arithmetic(None, 0) == N.ERR_ARG
+    if lib.hnswgpu_device_count() == 0:
+        with pytest.raises(native.HnswError) as e:
+            native.eval_distance_matrix("DistL2", uniform(2, 8, 1), uniform(3, 8, 2), batch=2, arithmetic="simd8")
+        assert e.value.code == N.ERR_DEVICE
+    with pytest.raises(native.HnswError) as e:  # the probability distances have no SIMD-order variant
+        native.eval_distance_matrix("DistHellinger", uniform(2, 8, 1), uniform(3, 8, 2), batch=2, arithmetic="simd8")
+    assert e.value.code in (N.ERR_ARG, N.ERR_DEVICE)
+
+
 def test_empty_index_search_returns_empty(native):
     h = native.Hnsw(8, 10, 16, 20, "DistL2")
     assert h.parallel_search(uniform(3, 4, 1), 2, 5) == [[], [], []]  # src/hnsw.rs:1498-1503

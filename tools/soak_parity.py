@@ -23,6 +23,9 @@ ap.add_argument("--config", default="sift1m", choices=sorted(bench.CONFIGS))
 ap.add_argument("--batches", type=int, default=8)
 ap.add_argument("--seed-base", type=lambda v: int(v, 0), default=0xABCD0000, help="batch b is drawn with seed base + b")
 ap.add_argument("--points-as-queries", type=int, default=0, help="this many queries of every batch are stored points (distance 0, duplicates' ties)")
+ap.add_argument("--simd8", action="store_true", help="both sides in the SIMD summation order (hnswgpu_set_arithmetic / the oracle's set_simd_order)")
+ap.add_argument("--filtered", type=int, default=0, metavar="N", help="additionally, per batch: the first N queries through search_filter "
+                "with a fresh random filter allowing 1 % (even batches) or 30 % (odd batches) of the points")
 ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
 args = ap.parse_args()
 cfg = bench.CONFIGS[args.config]
@@ -36,7 +39,10 @@ h.upload(0)
 o = oracle_lib.OracleHnsw.load(args.cache_dir, base, cfg["dist"])
 k, ef, d, nq = cfg["k"], cfg["ef"], cfg["d"], cfg["nq"]
 dm = H.DataMap.from_hnswdump(args.cache_dir, base) if args.points_as_queries else None
-bad = checked = ties = 0
+if args.simd8:
+    h.set_arithmetic("simd8")
+    o.set_simd_order(True)
+bad = checked = ties = fbad = fchecked = 0
 t0 = time.time()
 for b in range(args.batches):
     Q = bench.synth(nq, d, args.seed_base + b, "clustered" if b % 2 == 0 else "uniform")
@@ -52,6 +58,22 @@ for b in range(args.batches):
           & np.all(res.layers == ref.layers, axis=1) & np.all(res.ranks == ref.ranks, axis=1) & (res.counts == ref.counts))
     bad += int((~ok).sum())
     checked += nq
-print(f"{args.config}: {checked} queries in {args.batches} batches ({time.time() - t0:.1f} s), {ties} answered through the literal heaps, "
+    if args.filtered:
+        nf = min(nq, args.filtered)
+        n = h.get_nb_point()
+        pct = 1 if b % 2 == 0 else 30
+        allowed = np.sort(np.random.default_rng(args.seed_base + 77 + b).choice(n, max(1, n * pct // 100), replace=False)).astype(np.uint64)
+        fr = h.parallel_search_filter_flat(Q[:nf], k, ef, allowed)
+        fo = o.parallel_search_filter(Q[:nf], k, ef, allowed)
+        fok = (fr.counts == fo.counts)
+        for i in range(nf):
+            c = int(fo.counts[i])
+            fok[i] = fok[i] and np.array_equal(fr.ids[i, :c], fo.ids[i, :c]) and np.array_equal(fr.dists[i, :c].view(np.uint32), fo.dists[i, :c].view(np.uint32))
+        fbad += int((~fok).sum())
+        fchecked += nf
+if args.filtered:
+    print(f"{args.config}: {fchecked} filtered queries (1 % / 30 % allowed alternating), {fbad} differ from the oracle")
+    bad += fbad
+print(f"{args.config}{' (SIMD-order arithmetic)' if args.simd8 else ''}: {checked} queries in {args.batches} batches ({time.time() - t0:.1f} s), {ties} answered through the literal heaps, "
       f"{bad} differ from the oracle")
 sys.exit(1 if bad else 0)
