@@ -802,6 +802,12 @@ def main():
         cpu_baseline, parity = cpu_baseline_leg(args.cache_dir, base, cfg["dist"], Q, k, ef, res_ids, out_dists.cpu().numpy(),
                                                 st, cnt, args.cpu_seconds, orc)
 
+    if cpu_baseline is not None:
+        # the device's figure in the SAME arithmetic as cpu_baseline.value (which is the better of the port's two orders):
+        # `value` itself is always the scalar order, the one the parity block checks
+        simd = cpu_baseline.get("arithmetic", "").startswith("simd")
+        cpu_baseline["device_queries_per_s_in_the_same_arithmetic"] = (None if simd_qps is None else round(simd_qps, 1)) if simd else round(qps, 1)
+        cpu_baseline["scalar_order_value"] = max(cpu_baseline["by_threads"].values())
     if rank == 0:
         out = {
             "metric": "queries/sec (+ recall@10), batched HNSW search",

@@ -10,11 +10,12 @@ DeviceIndex::DeviceIndex() {}
 DeviceIndex::~DeviceIndex() {}
 int DeviceIndex::upload(const FlatIndex&, int, std::string& err) { err = kNoDev; return ERR_DEVICE; }
 int DeviceIndex::search_device(const float*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*, uint32_t*,
-                               void*, const uint64_t*, uint64_t, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+                               void*, const uint64_t*, uint64_t, CallInfo*, std::string& err, const RowFeed*) { err = kNoDev; return ERR_DEVICE; }
 int DeviceIndex::search_host(const float*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*,
                              const uint64_t*, uint64_t, bool, uint8_t*, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
 int DeviceIndex::search_host_staged(const float*, const float* const*, uint64_t, uint64_t, uint64_t, uint64_t, const uint64_t*, uint64_t, bool,
-                                    bool, AnswerSink, void*, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+                                    bool, const AnswerSink&, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+int DeviceIndex::kernel_metric() const { return dist_; }
 CallInfo DeviceIndex::last_call() const { return CallInfo{}; }
 int device_count() { return 0; }
 namespace {
@@ -29,5 +30,5 @@ public:
 };
 }  // namespace
 std::unique_ptr<BuildSearchBackend> make_device_build_backend(int) { return std::unique_ptr<BuildSearchBackend>(new NoDeviceBackend()); }
-int eval_distance_matrix_device(int, const float*, uint64_t, const float*, uint64_t, uint64_t, uint32_t, bool, float*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+int eval_distance_matrix_device(int, const float*, uint64_t, const float*, uint64_t, uint64_t, uint32_t, bool, float*, std::string& err, int) { err = kNoDev; return ERR_DEVICE; }
 }  // namespace hnswgpu
