@@ -71,6 +71,9 @@ for b in range(args.batches):
             fok[i] = fok[i] and np.array_equal(fr.ids[i, :c], fo.ids[i, :c]) and np.array_equal(fr.dists[i, :c].view(np.uint32), fo.dists[i, :c].view(np.uint32))
         fbad += int((~fok).sum())
         fchecked += nf
+        for i in np.nonzero(~fok)[0][:4]:
+            print(f"  batch {b} ({pct} % allowed, filter seed {args.seed_base + 77 + b:#x}), query {i}: counts {fr.counts[i]} / {fo.counts[i]}, status {fr.status[i]} / {fo.status[i]}\n"
+                  f"    device ids {fr.ids[i].tolist()}\n    oracle ids {fo.ids[i].tolist()}\n    device d {fr.dists[i].tolist()}\n    oracle d {fo.dists[i].tolist()}")
 if args.filtered:
     print(f"{args.config}: {fchecked} filtered queries (1 % / 30 % allowed alternating), {fbad} differ from the oracle")
     bad += fbad
