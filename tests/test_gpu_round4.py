@@ -89,6 +89,23 @@ def test_config4_100k_queries_in_8_shards_on_1m_x_128(native, oracle, sift1m):
     assert h.last_tie_count() > 0
 
 
+def test_filtered_search_at_full_size(native, oracle, sift1m):
+    """Hnsw::search_filter with a sorted id vector on the 1M x 128 index, 1 % and 30 % of the points allowed: clustered queries,
+    stored points, and uniform queries that wander far from every cluster (thousands of candidates accepted per query: candidate
+    heaps beyond their LDS part, runs of pushes across powers of two -- the case the round-4 soak caught) == the oracle's
+    search_filter: ids, distance bits, p_ids, counts, panic flags (src/hnsw.rs:1487-1580)."""
+    h, o, stored = sift1m
+    h.upload(0)
+    k, ef, n = 10, 64, 1_000_000
+    Q = np.concatenate([_clustered(384, 128, 0x5EED0007), stored[:128], np.random.default_rng(9).random((256, 128), dtype=np.float32)])
+    for pct, seed in ((1, 21), (30, 22)):
+        allowed = np.sort(np.random.default_rng(seed).choice(n, n * pct // 100, replace=False)).astype(np.uint64)
+        got = h.parallel_search_filter_flat(Q, k, ef, allowed)
+        ref = o.parallel_search_filter(Q, k, ef, allowed)
+        assert np.array_equal(got.status, ref.status)
+        assert_same(got, ref)
+
+
 # ------------------------------------------------------------------------------------------------- SIMD-order arithmetic (opt-in)
 SIMD8_DIMS = list(range(1, 131)) + [136, 159, 160, 161, 200, 255, 256, 257, 300, 383, 384, 500, 511, 512, 640, 767, 768, 783, 784, 785, 800]
 
