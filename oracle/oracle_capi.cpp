@@ -309,8 +309,8 @@ int orc_heap_retain(const float* vals, const int32_t* tags, const uint8_t* keep,
 
 // Scripted BinaryHeap driver: step i pushes (vals[i], tags[i]) when is_pop[i] == 0, else pops.  out_* receive
 // the popped entries in order (returns their number through *npopped); sorted_* receive into_sorted_vec of what
-// is left (returns its length).  Used to check the device's lane-parallel heap algorithms (emulated in Python,
-// tests/test_heap_algorithms.py) against the literal restatement on interleaved pushes and pops with ties.
+// is left (returns its length).  Used by the second Python transcription of std's BinaryHeap (tests/test_oracle.py,
+// tests/test_second_opinion.py) and by the pin probes (tests/golden/make_pin_probes.py) on interleaved pushes and pops with ties.
 int orc_heap_script(const float* vals, const int32_t* tags, const uint8_t* is_pop, size_t n, float* out_vals,
                     int32_t* out_tags, size_t* npopped, float* sorted_vals, int32_t* sorted_tags) {
     ORC_TRY
