@@ -181,3 +181,54 @@ def test_simd8_full_size_config2(native, oracle, sift1m):
     finally:
         h.set_arithmetic("scalar")
         o.set_simd_order(False)
+
+
+# ------------------------------------------------------------------------------------------------- DistCosine on hostile exponents
+@pytest.mark.parametrize("d", [1, 3, 5, 25, 29, 30, 45, 61, 62, 100, 125, 126])
+def test_cosine_f64_chain_on_hostile_exponent_ranges(native, oracle, d):
+    """DistCosine's three sums (anndists: f32 products widened to f64, added left to right) on rows where the ORDER of the
+    additions decides the bits: components spread over 2^-40..2^40, subnormal components, products that underflow, values near
+    2^61, exact cancellation, signed zeros, all-zero rows, exact powers of two -- in batches of 1 to 64 rows (4 and 2 lanes per
+    row, one and two rounds), with the norm inside the row (d + 2 <= row_stride) or beside it.  Written while measuring a sum
+    that leaves the chain when the exponent windows prove no addition can round (it lost to the chain on the
+    device and was dropped); the inputs stay as the sharpest test of the chain's order.  Tolerance: 0 ulp."""
+    rng = np.random.default_rng(7000 + d)
+    n = 128
+    X = (rng.random((n, d), dtype=np.float32) - np.float32(0.5))
+    X[8:16] *= np.exp2(rng.integers(-40, 41, (8, d))).astype(np.float32)          # wide windows
+    X[16:20] *= np.float32(1e-30)                                                  # tiny but normal: products underflow against tiny queries
+    X[20:24] *= np.float32(2.0 ** 61)                                              # large: the overflow bound of the test, not crossed
+    X[24, :: max(1, d // 3)] = np.float32(1e-42)                                   # subnormal components
+    X[25] = 0.0
+    X[26, ::2] = -0.0
+    X[27] = np.float32(2.0) ** rng.integers(-3, 4, d)                              # exact powers of two
+    X[64 + 5] *= np.exp2(rng.integers(-60, 61, d)).astype(np.float32)              # one failing row in an otherwise plain batch
+    Q = (rng.random((12, d), dtype=np.float32) - np.float32(0.5))
+    Q[1] = X[2]
+    Q[2] = -X[3]                                                                    # cosine -1 ... +1, cancellation inside the sum
+    Q[3] *= np.exp2(rng.integers(-30, 31, d)).astype(np.float32)
+    Q[4] *= np.float32(1e-30)
+    Q[5] *= np.float32(2.0 ** 61)
+    Q[6, 0] = np.float32(1e-41)
+    Q[7] = 0.0
+    Q[8] = np.float32(2.0) ** rng.integers(-3, 4, d)
+    if d > 1:
+        Q[9, 1::2] = -Q[9, 1::2]
+    want = oracle.dist_matrix("DistCosine", Q, X).view(np.uint32)
+    for batch in (1, 16, 17, 32, 33, 64):
+        got = native.eval_distance_matrix("DistCosine", Q, X, batch=batch).view(np.uint32)
+        assert np.array_equal(got, want), (d, batch, np.argwhere(got != want)[:5])
+
+
+def test_cosine_products_in_the_subnormal_range(native, oracle):
+    """Query and rows scaled by 2^-70: every product lands in f32's subnormal range (or at zero); the device keeps f32
+    subnormals like the host does, and the sums equal the oracle's."""
+    rng = np.random.default_rng(7999)
+    for d in (7, 25, 61, 125):
+        X = (rng.random((40, d), dtype=np.float32) - np.float32(0.5)) * np.float32(2.0 ** -70)
+        Q = (rng.random((4, d), dtype=np.float32) - np.float32(0.5)) * np.float32(2.0 ** -70)
+        Q[3] *= np.float32(2.0 ** 70)
+        want = oracle.dist_matrix("DistCosine", Q, X).view(np.uint32)
+        for batch in (16, 33):
+            got = native.eval_distance_matrix("DistCosine", Q, X, batch=batch).view(np.uint32)
+            assert np.array_equal(got, want), (d, batch)
