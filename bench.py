@@ -342,12 +342,13 @@ def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, cpu_queries, pct
     return out
 
 
-def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=5):
+def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=25):
     """What a caller pays above the device-buffer call (reported next to `value`, never as `value`):
-    * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (H2D + kernels + D2H);
+    * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (the queries read across PCIe by the descent
+      kernel, the answers written into a pinned arena and unpacked), output arrays reused / allocated per call;
     * ffi: the reference's own symbol parallel_search_neighbours_f32 (src/libext.rs:205-254) on a handle loaded the
-      reference's way (get_hnswio + load_hnswdump_f32_<Dist>): array of row pointers in, Vec_api<Neighbourhood_api> out,
-      freed with hnswgpu_free_neighbourhood_vec;
+      reference's way (get_hnswio + load_hnswdump_f32_<Dist>): array of row pointers in, Vec_api<Neighbourhood_api> out --
+      written in place by the search kernels (a page-locked slab) --, freed with hnswgpu_free_neighbourhood_vec;
     * filtered: Hnsw::search_filter with a sorted id vector allowing 1 % / 30 % of the points (literal-heap kernel)."""
     nq, d = Q.shape
     out = {}
@@ -361,7 +362,9 @@ def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, rep
             ts.append(time.perf_counter() - t0)
         return nq / float(np.median(ts))
 
-    out["host_buffers_queries_per_s"] = round(rate(lambda: index.parallel_search_flat(Q, k, ef)), 1)
+    reuse = index.parallel_search_flat(Q, k, ef)  # a caller in steady state writes the same output arrays again
+    out["host_buffers_queries_per_s"] = round(rate(lambda: index.parallel_search_flat(Q, k, ef, out=reuse)), 1)
+    out["host_buffers_fresh_output_arrays_queries_per_s"] = round(rate(lambda: index.parallel_search_flat(Q, k, ef)), 1)
     loader = getattr(lib, "load_hnswdump_f32_" + dist_name, None)
     if loader is not None:
         cwd = os.getcwd()

@@ -185,17 +185,24 @@ class Hnsw:
         _check(self._lib.hnswgpu_upload(self._h, device))
 
     # ---- search -------------------------------------------------------------------------
-    def parallel_search_flat(self, datas, knbn, ef):
-        """Hnsw::parallel_search on a (nq, d) matrix; returns a BatchResult (flat arrays)."""
+    def parallel_search_flat(self, datas, knbn, ef, out=None):
+        """Hnsw::parallel_search on a (nq, d) matrix; returns a BatchResult (flat arrays).  `out`: a BatchResult of an earlier
+        call of the same shape whose arrays are written again (a caller in steady state: fresh arrays cost a page fault per
+        4 KB while the answers are unpacked)."""
         datas = np.ascontiguousarray(datas, dtype=np.float32)
         if datas.ndim != 2:
             raise HnswError(N.ERR_ARG, "datas must be a (nq, d) matrix")
         nq, d = datas.shape
-        ids = np.zeros((nq, knbn), np.uint64)
-        dists = np.zeros((nq, knbn), np.float32)
-        layers = np.zeros((nq, knbn), np.uint8)
-        ranks = np.zeros((nq, knbn), np.int32)
-        counts = np.zeros(nq, np.uint32)
+        if out is not None:
+            ids, dists, layers, ranks, counts = out.ids, out.dists, out.layers, out.ranks, out.counts
+            if ids.shape != (nq, knbn) or counts.shape != (nq,):
+                raise HnswError(N.ERR_ARG, "out was made for another shape")
+        else:
+            ids = np.zeros((nq, knbn), np.uint64)
+            dists = np.zeros((nq, knbn), np.float32)
+            layers = np.zeros((nq, knbn), np.uint8)
+            ranks = np.zeros((nq, knbn), np.int32)
+            counts = np.zeros(nq, np.uint32)
         if self._h is None:  # empty index => empty answers (src/hnsw.rs:1498-1503)
             return BatchResult(ids, dists, layers, ranks, counts)
         _check(self._lib.hnswgpu_search_batch(self._h, _p(datas), nq, d, knbn, ef, _p(ids), _p(dists), _p(layers),

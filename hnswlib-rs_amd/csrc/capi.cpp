@@ -1,6 +1,7 @@
 // capi.cpp -- the C ABI declared in include/hnsw_mi355x.h: the thin hnswgpu_* entry points and the
 // name/layout-compatible replacements of the reference's own f32 FFI (src/libext.rs).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -916,51 +917,84 @@ const Neighbourhood_api* search_neighbours_f32(const HnswApif32* api, size_t len
 // hands the Vec_api pointer to hnswgpu_free_neighbourhood_vec, which finds the header in front of it).
 namespace {
 constexpr uint64_t SLAB_MAGIC = 0x486E7377536C6162ull;  // "HnswSlab"
+// A slab is ordinary memory, or -- the usual case -- page-locked memory the device addresses (hnswgpu::pinned_alloc): the search
+// kernels then write ids, distances and counts straight into the Neighbour_api / Neighbourhood_api records and the call has
+// no unpacking pass.  The header remembers which, and the shape (nq, k) whose row pointers the records hold.
 struct SlabHeader {
     uint64_t magic;
     uint64_t bytes;
+    uint64_t dev;      // page-locked: the address of this header as the allocating device sees it (nonzero); 0: ordinary memory
+    uint64_t nq, k;    // the shape the Neighbourhood_api records were last laid out for (0, 0: not yet)
+    uint64_t reserved;
 };
+static_assert(sizeof(SlabHeader) % 16 == 0, "the records behind the header stay 16-byte aligned");
 struct FfiAnswer {
     size_t nq, k;
     Vec_api_Neighbourhood* out;
     Neighbourhood_api* lists;
     Neighbour_api* rows;
+    SlabHeader* slab;
 };
 // A caller that frees its answers (hnswgpu_free_neighbourhood_vec) and asks again gets the same memory back: a 10 000 x 10
 // answer is a 1.9 MB allocation, which malloc serves with mmap / munmap and the kernel with ~470 fresh page faults per call --
-// a tenth of a millisecond on a 1.2 ms search.  A few freed slabs (at most 64 MB) are kept for the next call of the same size.
+// a tenth of a millisecond on a 1.2 ms search -- and page-locking costs more than that.  A few freed slabs (at most 64 MB) are
+// kept for the next call of the same size; at most 256 MB of page-locked slabs are out at any time (answers a caller never
+// frees -- the reference leaks them, src/libext.rs:236-253 -- are then served from ordinary memory, with an unpacking pass).
 class SlabCache {
 public:
-    void* take(size_t bytes) {
+    SlabHeader* take(size_t bytes, bool pinned_ok) {
         {
             std::lock_guard<std::mutex> g(mu_);
             for (size_t i = 0; i < n_; ++i)
-                if (slab_[i].bytes == bytes) {
-                    void* p = slab_[i].p;
+                if (slab_[i]->bytes == bytes && (pinned_ok || slab_[i]->dev == 0)) {
+                    SlabHeader* h = slab_[i];
                     slab_[i] = slab_[--n_];
                     held_ -= bytes;
-                    return p;
+                    h->magic = SLAB_MAGIC;
+                    return h;
                 }
         }
-        return std::malloc(bytes);
+        SlabHeader* h = nullptr;
+        if (pinned_ok) {
+            if (pinned_out_.fetch_add(bytes) + bytes <= PINNED_LIMIT) {
+                void* dev = nullptr;
+                h = static_cast<SlabHeader*>(hnswgpu::pinned_alloc(bytes, &dev));
+                if (h) {
+                    *h = SlabHeader{SLAB_MAGIC, bytes, (uint64_t)(uintptr_t)dev, 0, 0, 0};
+                    return h;
+                }
+            }
+            pinned_out_.fetch_sub(bytes);  // refused by the runtime, or over the limit: ordinary memory
+        }
+        h = static_cast<SlabHeader*>(std::malloc(bytes));
+        if (h) *h = SlabHeader{SLAB_MAGIC, bytes, 0, 0, 0, 0};
+        return h;
     }
-    void give(void* p, size_t bytes) {
+    void give(SlabHeader* h) {
+        const size_t bytes = (size_t)h->bytes;
+        h->magic = 0;  // (a second free of the same answer is then at least not taken for a slab)
         {
             std::lock_guard<std::mutex> g(mu_);
             if (n_ < KEEP && held_ + bytes <= (64ull << 20)) {
-                slab_[n_++] = Entry{p, bytes};
+                slab_[n_++] = h;
                 held_ += bytes;
                 return;
             }
         }
-        std::free(p);
+        if (h->dev != 0) {
+            hnswgpu::pinned_free(h);
+            pinned_out_.fetch_sub(bytes);
+        } else {
+            std::free(h);
+        }
     }
 private:
-    struct Entry { void* p; size_t bytes; };
     static constexpr size_t KEEP = 4;
+    static constexpr uint64_t PINNED_LIMIT = 256ull << 20;
     std::mutex mu_;
-    Entry slab_[KEEP] = {};
+    SlabHeader* slab_[KEEP] = {};
     size_t n_ = 0, held_ = 0;
+    std::atomic<uint64_t> pinned_out_{0};
 };
 SlabCache& slab_cache() {
     static SlabCache* c = new SlabCache();  // (never destroyed: answers may be freed during static destruction)
@@ -975,25 +1009,33 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
     hnswgpu_index* idx = api->idx;
     for (size_t i = 0; i < nb_vec; ++i)
         if (!data[i]) { fail(HNSWGPU_ERR_ARG, "parallel_search_neighbours_f32: null row pointer"); return nullptr; }
-    FfiAnswer ans{nb_vec, knbn, nullptr, nullptr, nullptr};
+    FfiAnswer ans{nb_vec, knbn, nullptr, nullptr, nullptr, nullptr};
     // the row pointers are gathered straight into pinned staging memory (the reference copies them into Vec<Vec<f32>>,
-    // :218-226); the slab is taken before the search starts and filled straight out of the pinned answer arena, by the
-    // threads of the call's pool section, range by range
+    // :218-226); the slab is taken before the search starts.  A page-locked slab is written by the search kernels themselves
+    // (sink.direct); an ordinary one is filled out of the pinned answer arena by the threads of the call's pool section
+    // (HNSWGPU_FFI_UNPACK=1 forces that path: test hook)
     DeviceIndex::AnswerSink sink{
         [](void* ctx, uint64_t nq, uint64_t k) -> bool {
             FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
             const size_t bytes = sizeof(SlabHeader) + sizeof(Vec_api_Neighbourhood) + nq * sizeof(Neighbourhood_api) + nq * k * sizeof(Neighbour_api);
-            unsigned char* slab = static_cast<unsigned char*>(slab_cache().take(bytes));
-            if (!slab) return false;
-            SlabHeader* h = reinterpret_cast<SlabHeader*>(slab);
-            h->magic = SLAB_MAGIC;
-            h->bytes = bytes;
+            const bool unpack_only = std::getenv("HNSWGPU_FFI_UNPACK") != nullptr;
+            SlabHeader* h = slab_cache().take(bytes, !unpack_only);
+            if (!h) return false;
+            unsigned char* slab = reinterpret_cast<unsigned char*>(h);
             Vec_api_Neighbourhood* v = reinterpret_cast<Vec_api_Neighbourhood*>(slab + sizeof(SlabHeader));
             f.lists = reinterpret_cast<Neighbourhood_api*>(v + 1);
             f.rows = reinterpret_cast<Neighbour_api*>(f.lists + nq);
             v->len = (int64_t)nq;
             v->ptr = f.lists;
             f.out = v;
+            f.slab = h;
+            if (h->dev != 0 && (h->nq != nq || h->k != k)) {
+                // the records the kernels do not write: every list's row pointer, the high word of its count, the rows' padding
+                std::memset(f.lists, 0, bytes - sizeof(SlabHeader) - sizeof(Vec_api_Neighbourhood));
+                for (size_t i = 0; i < nq; ++i) f.lists[i].neighbours = f.rows + i * k;
+                h->nq = nq;
+                h->k = k;
+            }
             return true;
         },
         [](void* ctx, const DeviceIndex::HostAnswers& a, uint64_t lo, uint64_t hi) {
@@ -1009,7 +1051,18 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
                 f.lists[i].neighbours = r;
             }
         },
-        &ans};
+        &ans,
+        [](void* ctx, DeviceIndex::DirectOut* out) -> bool {
+            FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
+            if (!f.slab || f.slab->dev == 0) return false;
+            static_assert(sizeof(Neighbour_api) == 16 && sizeof(Neighbourhood_api) == 16 && sizeof(size_t) == 8, "the in-place layout");
+            out->allocation = f.slab;
+            out->ids = &f.rows[0].id;
+            out->dists = &f.rows[0].d;
+            out->counts = &f.lists[0].nbgh;
+            out->layout = hnswgpu::OutLayout{16, 16, 16};
+            return true;
+        }};
     std::string err;
     int rc;
     {
@@ -1048,9 +1101,8 @@ void hnswgpu_free_neighbourhood(const Neighbourhood_api* p) {
 void hnswgpu_free_neighbourhood_vec(const Vec_api_Neighbourhood* p) {
     if (!p) return;
     SlabHeader* h = reinterpret_cast<SlabHeader*>(reinterpret_cast<unsigned char*>(const_cast<Vec_api_Neighbourhood*>(p)) - sizeof(SlabHeader));
-    const uint64_t bytes = h->bytes;
-    h->magic = 0;  // (a second free of the same answer is then at least not taken for a slab by the cache)
-    slab_cache().give(h, (size_t)bytes);
+    if (h->magic != SLAB_MAGIC) return;  // not an answer of this library, or freed already
+    slab_cache().give(h);
 }
 
 int64_t file_dump_f32(const HnswApif32* api, size_t namelen, const uint8_t* filename) {

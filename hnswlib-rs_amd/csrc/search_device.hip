@@ -166,6 +166,16 @@ struct PinnedBuf {
     }
 };
 
+void* pinned_alloc(size_t bytes, void** dev) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostGetDevicePointer(dev, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return nullptr; }
+    return p;
+}
+void pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 struct DeviceIndex::Workspace {
     DevBuf qpad, tie, pre, order, retry[2], stats, bitmap, heaps, cand, oplog, allow, allowed_ids;
     PinnedBuf pin_in, pin_out;
@@ -380,7 +390,7 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
 int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_qlist, uint32_t nq, uint64_t k, uint64_t ef,
                            const uint32_t* d_allow, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
                            int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* stats, void* stream_v, uint32_t* panics,
-                           std::string& err) {
+                           std::string& err, OutLayout layout) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const uint32_t tile_bytes = tile_bytes_for(kernel_metric(), v_.row_stride);
     const uint32_t bitmap_words = (v_.n + 31) / 32;
@@ -432,6 +442,9 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
         a.out_layer = d_out_layer;
         a.out_rank = d_out_rank;
         a.out_counts = d_out_counts;
+        a.id_stride = layout.id_stride;
+        a.dist_stride = layout.dist_stride;
+        a.count_stride = layout.count_stride;
         a.stats = stats;
         a.pre = w.pre.as<PreDescent>();
         x.heaps = w.heaps.as<hent_t>();
@@ -455,7 +468,7 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
 int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef_arg,
                                uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank,
                                uint32_t* d_out_counts, uint32_t* d_stats, void* stream_v, const uint64_t* d_allowed,
-                               uint64_t n_allowed, CallInfo* info_out, std::string& err, const RowFeed* feed) {
+                               uint64_t n_allowed, CallInfo* info_out, std::string& err, const RowFeed* feed, OutLayout layout) {
     if (!ready_) { err = "index is not resident on a device: call hnswgpu_upload first"; return ERR_DEVICE; }
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
     CallInfo info{};
@@ -531,7 +544,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         }
         HIP_TRY(hipEventRecord(w.ev_ks, stream));
         int rc = run_exact(w, w.qpad.as<float>(), nullptr, (uint32_t)nq, k, ef, d_allow, d_out_ids, d_out_dists, d_out_layer, d_out_rank,
-                           d_out_counts, stats, stream, &info.panics, err);
+                           d_out_counts, stats, stream, &info.panics, err, layout);
         if (rc != OK) return rc;
         HIP_TRY(hipEventRecord(w.ev_stop, stream));
         HIP_TRY(wait_event(w.ev_stop));
@@ -653,6 +666,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         a.out_layer = d_out_layer;
         a.out_rank = d_out_rank;
         a.out_counts = d_out_counts;
+        a.id_stride = layout.id_stride;
+        a.dist_stride = layout.dist_stride;
+        a.count_stride = layout.count_stride;
         a.stats = stats;
         a.pre = w.pre.as<PreDescent>();
         {
@@ -718,7 +734,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     if (strict_ties && n_flagged > 0) {
         // the flagged queries again, with both heaps literal from the first operation on
         int rc = run_exact(w, w.qpad.as<float>(), w.tie.as<uint32_t>(), n_flagged, k, ef, nullptr, d_out_ids, d_out_dists, d_out_layer,
-                           d_out_rank, d_out_counts, stats, stream, nullptr, err);
+                           d_out_rank, d_out_counts, stats, stream, nullptr, err, layout);
         if (rc != OK) return rc;
         ++launches;
     }
@@ -824,6 +840,15 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     };
     if (sink.begin && !sink.begin(sink.ctx, nq, k)) { err = "out of memory"; return ERR_ARG; }
+    DirectOut direct{};
+    const bool in_place = !want_status && sink.direct && sink.direct(sink.ctx, &direct);
+    unsigned char* direct_dev = nullptr;  // the sink's allocation as this device addresses it
+    if (in_place) {
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, direct.allocation, 0));
+        direct_dev = static_cast<unsigned char*>(dp);
+    }
+    auto in_sink = [&](void* host) { return direct_dev + (static_cast<unsigned char*>(host) - static_cast<unsigned char*>(direct.allocation)); };
     const uint64_t q_bytes = nq * d * sizeof(float);
     const uint64_t o_ids = 0, o_dists = o_ids + nq * k * sizeof(uint64_t), o_rank = o_dists + nq * k * sizeof(float),
                    o_layer = o_rank + nq * k * sizeof(int32_t), o_cnt = (o_layer + nq * k + 7) & ~7ull,
@@ -841,8 +866,14 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     }
     // how many threads, how the work is cut: ~64 KB per gather task, a few chunks (every chunk is a launch of the descent kernel)
     const uint64_t total_bytes = q_bytes + o_ans_end;
-    const unsigned nt = total_bytes < (256u << 10) ? 1u : (unsigned)std::min<uint64_t>(8, std::max<uint64_t>(2, total_bytes / (256u << 10)));
-    const uint64_t n_chunks = nt == 1 ? 1 : std::min<uint64_t>(4, std::max<uint64_t>(1, nq / 1024));
+    // (measured, tools/host_call_sweep.py: 2 chunks beat 4 and 1 -- every chunk is a launch of the descent kernel, whose reads across
+    // PCIe are what the front of the call waits for, not the gather; 4 to 8 threads are equal, more are slower)
+    uint64_t max_threads = 8, max_chunks = 2;
+    if (const char* e = std::getenv("HNSWGPU_HOST_THREADS")) max_threads = (uint64_t)std::max(1, std::atoi(e));  // tuning hooks
+    if (const char* e = std::getenv("HNSWGPU_HOST_CHUNKS")) max_chunks = (uint64_t)std::max(1, std::atoi(e));
+    const unsigned nt = total_bytes < (256u << 10) || max_threads == 1 ? 1u
+                        : (unsigned)std::min<uint64_t>(max_threads, std::max<uint64_t>(2, total_bytes / (256u << 10)));
+    const uint64_t n_chunks = nt == 1 ? 1 : std::min<uint64_t>(max_chunks, std::max<uint64_t>(1, nq / 1024));
     HostCall hc(n_chunks);
     hc.queries = queries; hc.rows = rows; hc.hq = static_cast<float*>(w.pin_in.p);
     hc.d = d; hc.nq = nq; hc.n_chunks = n_chunks;
@@ -881,15 +912,20 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         if (std::this_thread::get_id() == caller && !main_taken.exchange(true)) {
             // the caller: the device side of the call (its launches wait for the chunks), then its share of the unpacking
             const auto t_search = std::chrono::steady_clock::now();
-            rc = search_device(static_cast<const float*>(w.pin_in.dev), nq, d, k, ef, reinterpret_cast<uint64_t*>(dout + o_ids),
-                               reinterpret_cast<float*>(dout + o_dists), dout + o_layer, reinterpret_cast<int32_t*>(dout + o_rank),
-                               reinterpret_cast<uint32_t*>(dout + o_cnt), want_status ? reinterpret_cast<uint32_t*>(dout + o_stat) : nullptr,
-                               stream, dallowed, filtered ? n_allowed : 0, info, err, &feed);
+            if (in_place)
+                rc = search_device(static_cast<const float*>(w.pin_in.dev), nq, d, k, ef, reinterpret_cast<uint64_t*>(in_sink(direct.ids)),
+                                   reinterpret_cast<float*>(in_sink(direct.dists)), nullptr, nullptr, reinterpret_cast<uint32_t*>(in_sink(direct.counts)),
+                                   nullptr, stream, dallowed, filtered ? n_allowed : 0, info, err, &feed, direct.layout);
+            else
+                rc = search_device(static_cast<const float*>(w.pin_in.dev), nq, d, k, ef, reinterpret_cast<uint64_t*>(dout + o_ids),
+                                   reinterpret_cast<float*>(dout + o_dists), dout + o_layer, reinterpret_cast<int32_t*>(dout + o_rank),
+                                   reinterpret_cast<uint32_t*>(dout + o_cnt), want_status ? reinterpret_cast<uint32_t*>(dout + o_stat) : nullptr,
+                                   stream, dallowed, filtered ? n_allowed : 0, info, err, &feed);
             us_search = since(t_search);
             // (search_device returns with the stream idle: the answers are in the arena -- or the call failed, and whatever
             // it left in flight is waited for by `drain`; the gather is then finished by nobody, which is fine)
-            hc.phase.store(rc == OK ? 2 : 3, std::memory_order_release);
-            if (rc == OK) {
+            hc.phase.store(rc == OK && !in_place ? 2 : 3, std::memory_order_release);  // (in place: nothing to unpack)
+            if (rc == OK && !in_place) {
                 const auto t0 = std::chrono::steady_clock::now();
                 hc.unpack_all();
                 hc.us_unpack = since(t0);

@@ -44,6 +44,17 @@ struct CallInfo {
 // One replica of an index in the HBM of one device.  The replica is immutable after upload(); every search call takes
 // a private workspace (scratch buffers, events, counters) from a pool, so concurrent calls on one replica are legal --
 // like the reference's `&self` search (SURVEY.md 8b "Threading").
+// Where answer j of query q is written, in bytes from the three base addresses a search is given: ids at (q k + j) id_stride,
+// distances at (q k + j) dist_stride, counts at q count_stride.  The default is three dense arrays; {16, 16, 16} addresses the
+// records of the reference's FFI in place (Neighbour_api {usize id; f32 d}, Neighbourhood_api {i64 nbgh; ptr}: src/libext.rs:58-87).
+struct OutLayout {
+    uint32_t id_stride = 8, dist_stride = 4, count_stride = 4;
+};
+// Host memory every device of the process can address (mapped, portable, page-locked): *dev receives the address the kernels
+// use.  nullptr when the runtime refuses (no device, limits): the caller falls back to ordinary memory and an unpacking pass.
+void* pinned_alloc(size_t bytes, void** dev);
+void pinned_free(void* p);
+
 class DeviceIndex {
 public:
     DeviceIndex();
@@ -69,10 +80,11 @@ public:
         void* ctx;
         uint64_t chunk_rows;  // rows per chunk (the feeder's choice: its gather tasks are cut along these)
     };
+    // `layout`: where the answers go relative to d_out_ids / d_out_dists / d_out_counts (OutLayout; default: dense arrays)
     int search_device(const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* d_out_ids,
                       float* d_out_dists, uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts,
                       uint32_t* d_stats, void* stream, const uint64_t* d_allowed, uint64_t n_allowed, CallInfo* info,
-                      std::string& err, const RowFeed* feed = nullptr);
+                      std::string& err, const RowFeed* feed = nullptr, OutLayout layout = OutLayout{});
     // same with host buffers (H2D + kernels + D2H); out_status (may be null): per query, 1 = the reference panics
     int search_host(const float* queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef, uint64_t* out_ids,
                     float* out_dists, uint8_t* out_layer, int32_t* out_rank, uint32_t* out_counts,
@@ -94,10 +106,22 @@ public:
         const uint32_t* counts;   // [nq]
         const uint8_t* status;    // [nq] filtered search: 1 = the reference panics on this query (else nullptr)
     };
+    // A sink whose own memory the device can address (pinned_alloc) may take the answers IN PLACE: `direct` (may be null; called
+    // after begin) names the allocation and, inside it, the first id / distance / count slot (host addresses) with their strides
+    // and returns true -- the kernels then write there (the device's view of the allocation is looked up per call, on the
+    // index's device), rows() is never called and nothing is unpacked (no layer / rank / status).
+    struct DirectOut {
+        void* allocation;   // what pinned_alloc returned
+        void* ids;
+        void* dists;
+        void* counts;
+        OutLayout layout;
+    };
     struct AnswerSink {
         bool (*begin)(void* ctx, uint64_t nq, uint64_t k);  // false: out of memory
         void (*rows)(void* ctx, const HostAnswers& a, uint64_t lo, uint64_t hi);
         void* ctx;
+        bool (*direct)(void* ctx, DirectOut* out) = nullptr;
     };
     int search_host_staged(const float* queries, const float* const* rows, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
                            const uint64_t* allowed, uint64_t n_allowed, bool filtered, bool want_status, const AnswerSink& sink,
@@ -122,7 +146,7 @@ private:
     int run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_qlist, uint32_t nq, uint64_t k, uint64_t ef,
                   const uint32_t* d_allow, uint64_t* d_out_ids, float* d_out_dists, uint8_t* d_out_layer,
                   int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* stats, void* stream, uint32_t* panics,
-                  std::string& err);
+                  std::string& err, OutLayout layout);
 
     DeviceIndexView v_{};
     bool ready_ = false;

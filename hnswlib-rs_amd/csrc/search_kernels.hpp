@@ -80,6 +80,11 @@ struct SearchArgs {
     const PreDescent* pre;  // [nq_total] what hnsw_descend_kernel left for every query: entry point of the search layer, its distance
     uint32_t* stats;        // [nq_total][8] = n_dist, n_expand, n_ids_read, status, t_start, t_end (10 ns ticks), bitmap_used,
                             // flags | (lists scanned by the descent << 8) | (n_dist of the descent << 16)
+    // where answer j of query q goes: out_ids + (q k + j) id_stride bytes, out_dists + (q k + j) dist_stride, out_counts + q
+    // count_stride.  8 / 4 / 4: three dense arrays.  16 / 16 / 16: the records the reference's FFI hands out -- out_ids is then
+    // the `id` field of the first Neighbour_api {usize id; f32 d}, out_dists its `d` field, out_counts the low word of the
+    // first Neighbourhood_api {i64 nbgh; ptr} (src/libext.rs:58-87) -- written in place, no unpacking pass on the host
+    uint32_t id_stride, dist_stride, count_stride;
 };
 
 struct ExactArgs {

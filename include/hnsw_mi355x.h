@@ -352,7 +352,8 @@ void init_rust_log(void);                                                       
  * (SURVEY.md 8b "Ownership").  These are additions.
  * hnswgpu_free_neighbourhood releases what search_neighbours_f32 returned (the struct and its row).
  * hnswgpu_free_neighbourhood_vec releases what parallel_search_neighbours_f32 returned, and is the ONLY way to release
- * it: the answer is one allocation (Vec_api | Neighbourhood_api[nb_vec] | every Neighbour_api row), so `ptr` and each
+ * it: the answer is one allocation (Vec_api | Neighbourhood_api[nb_vec] | every Neighbour_api row) -- usually page-locked
+ * memory the search kernels wrote in place, which free() cannot release at all --, so `ptr` and each
  * `neighbours` are interior pointers -- never free() a row or hand one of its Neighbourhood_api to
  * hnswgpu_free_neighbourhood, and never pass a Vec_api this library did not return.                                   */
 void hnswgpu_free_neighbourhood(const Neighbourhood_api* p);

@@ -10,7 +10,7 @@ DeviceIndex::DeviceIndex() {}
 DeviceIndex::~DeviceIndex() {}
 int DeviceIndex::upload(const FlatIndex&, int, std::string& err) { err = kNoDev; return ERR_DEVICE; }
 int DeviceIndex::search_device(const float*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*, uint32_t*,
-                               void*, const uint64_t*, uint64_t, CallInfo*, std::string& err, const RowFeed*) { err = kNoDev; return ERR_DEVICE; }
+                               void*, const uint64_t*, uint64_t, CallInfo*, std::string& err, const RowFeed*, OutLayout) { err = kNoDev; return ERR_DEVICE; }
 int DeviceIndex::search_host(const float*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*,
                              const uint64_t*, uint64_t, bool, uint8_t*, CallInfo*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
 int DeviceIndex::search_host_staged(const float*, const float* const*, uint64_t, uint64_t, uint64_t, uint64_t, const uint64_t*, uint64_t, bool,
@@ -18,6 +18,8 @@ int DeviceIndex::search_host_staged(const float*, const float* const*, uint64_t,
 int DeviceIndex::kernel_metric() const { return dist_; }
 CallInfo DeviceIndex::last_call() const { return CallInfo{}; }
 int device_count() { return 0; }
+void* pinned_alloc(size_t, void**) { return nullptr; }  // (no device: the callers fall back to ordinary memory)
+void pinned_free(void*) {}
 namespace {
 class NoDeviceBackend : public BuildSearchBackend {
 public:

@@ -232,3 +232,88 @@ def test_cosine_products_in_the_subnormal_range(native, oracle):
         for batch in (16, 33):
             got = native.eval_distance_matrix("DistCosine", Q, X, batch=batch).view(np.uint32)
             assert np.array_equal(got, want), (d, batch)
+
+
+# ------------------------------------------------------------------------------------------------- the FFI's answers written in place
+def _ffi_answers(lib, res, nq):
+    out = []
+    for i in range(nq):
+        nb = res.contents.ptr[i]
+        out.append([(nb.neighbours[j].id, nb.neighbours[j].d) for j in range(nb.nbgh)])
+    return out
+
+
+def test_ffi_answers_written_in_place_equal_the_unpacked_ones(native, oracle, tmp_path, monkeypatch):
+    """parallel_search_neighbours_f32 (src/libext.rs:205-254): the search kernels write ids, distances and counts straight into
+    the Neighbour_api / Neighbourhood_api records of a page-locked slab (no unpacking pass).  The records equal the oracle's
+    answers and those of the unpacking path (HNSWGPU_FFI_UNPACK=1: ordinary memory filled from the pinned arena); a freed slab
+    comes back for the next call of the same shape and is laid out again for another shape; answers held by the caller stay
+    valid while later calls run; ef > 1024 goes through the literal-heap kernel's writer; 300 answers never freed (the
+    reference leaks them all) pass the page-locked limit and are served from ordinary memory."""
+    from conftest import uniform
+    lib = native.lib()
+    n, d = 6000, 20
+    X = uniform(n, d, 51)
+    X[100:140] = X[200:240]  # exact ties
+    o = oracle.OracleHnsw(12, n, 16, 80, "DistL2")
+    o.insert_batch(X)
+    o.file_dump(tmp_path, "ffi")
+    monkeypatch.chdir(tmp_path)
+    io = lib.get_hnswio(3, b"ffi")
+    api = lib.load_hnswdump_f32_DistL2(io)
+    assert api
+    nq = 700
+    Q = uniform(nq, d, 52)
+    Q[:40] = X[100:140]
+    ptrs = (C.c_void_p * nq)(*[Q[i].ctypes.data for i in range(nq)])
+
+    def expect(k, ef, m=nq):
+        ref = o.parallel_search(Q[:m], k, ef)
+        return [[(int(ref.ids[i, j]), float(ref.dists[i, j])) for j in range(ref.counts[i])] for i in range(m)]
+
+    want = expect(7, 40)
+    res = lib.parallel_search_neighbours_f32(api, nq, d, ptrs, 7, 40)
+    assert res and res.contents.len == nq
+    assert _ffi_answers(lib, res, nq) == want
+    first_addr = C.addressof(res.contents)
+    # a second answer while the first is held: another slab, the first untouched
+    res2 = lib.parallel_search_neighbours_f32(api, nq, d, ptrs, 7, 40)
+    assert C.addressof(res2.contents) != first_addr
+    assert _ffi_answers(lib, res2, nq) == want and _ffi_answers(lib, res, nq) == want
+    lib.hnswgpu_free_neighbourhood_vec(res)
+    lib.hnswgpu_free_neighbourhood_vec(res2)
+    # freed slabs come back; another shape of the same size in bytes lays the records out again
+    res = lib.parallel_search_neighbours_f32(api, nq, d, ptrs, 7, 40)
+    assert C.addressof(res.contents) in (first_addr, C.addressof(res2.contents))
+    assert _ffi_answers(lib, res, nq) == want
+    lib.hnswgpu_free_neighbourhood_vec(res)
+    res = lib.parallel_search_neighbours_f32(api, nq // 2, d, ptrs, 15, 40)   # 350 x (16 + 15 x 16) == 700 x (16 + 7 x 16)
+    assert _ffi_answers(lib, res, nq // 2) == expect(15, 40, nq // 2)
+    lib.hnswgpu_free_neighbourhood_vec(res)
+    # the literal-heap kernel's writer (ef > 1024)
+    res = lib.parallel_search_neighbours_f32(api, 64, d, ptrs, 12, 1100)
+    assert _ffi_answers(lib, res, 64) == expect(12, 1100, 64)
+    lib.hnswgpu_free_neighbourhood_vec(res)
+    # the unpacking path gives the same records
+    monkeypatch.setenv("HNSWGPU_FFI_UNPACK", "1")
+    res = lib.parallel_search_neighbours_f32(api, nq, d, ptrs, 7, 40)
+    assert _ffi_answers(lib, res, nq) == want
+    lib.hnswgpu_free_neighbourhood_vec(res)
+    monkeypatch.delenv("HNSWGPU_FFI_UNPACK")
+    # answers that are never freed: beyond 256 MB of page-locked slabs the library hands out ordinary memory, still correct
+    big_q = 4000
+    Qb = np.tile(Q, (6, 1))[:big_q].copy()
+    pb = (C.c_void_p * big_q)(*[Qb[i].ctypes.data for i in range(big_q)])
+    refb = o.parallel_search(Qb[:50], 60, 64)
+    held = []
+    for it in range(80):  # 80 x 4000 x (16 + 60 x 16) bytes = 312 MB
+        r = lib.parallel_search_neighbours_f32(api, big_q, d, pb, 60, 64)
+        assert r
+        held.append(r)
+        if it in (0, 40, 79):
+            got = _ffi_answers(lib, r, 50)
+            assert got == [[(int(refb.ids[i, j]), float(refb.dists[i, j])) for j in range(refb.counts[i])] for i in range(50)]
+    for r in held:
+        lib.hnswgpu_free_neighbourhood_vec(r)
+    lib.drop_hnsw_f32(api)
+    lib.hnswgpu_free_hnswio(io)
