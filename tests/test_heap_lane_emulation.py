@@ -255,3 +255,190 @@ def test_into_sorted_vec_through_sift_down_range(ties):
             a.push((k(), t))
         data = list(a.d)
         assert dev_into_sorted_vec(data) == a.into_sorted_vec()
+
+
+# ------------------------------------------------------------------------------------------------- RegHeap: return_points in VGPRs
+class DevRegHeap:
+    """RegHeap<NS> (search_kernels.inc): entry i sits in slot i // 64 of lane i % 64; push, pop, the fused push + pop on a full
+    heap, sift_down_range -- with the slot arithmetic of chase() (children of slot k in slots 2k and 2k + 1, the right child of
+    a slot's last node in slot 2k + 2) restated lane by lane."""
+
+    def __init__(self, ns):
+        self.ns = ns
+        self.cap = 64 * ns
+        self.kc = 1 if ns == 1 else ns // 2
+        self.s = [[ZERO] * 64 for _ in range(ns)]
+
+    def get(self, i):
+        return self.s[i >> 6][i & 63] if (i >> 6) < self.ns else ZERO
+
+    def set(self, i, v):
+        if (i >> 6) < self.ns:
+            self.s[i >> 6][i & 63] = v
+
+    def push(self, ln, item):
+        pos = ln
+        while pos > 0:
+            parent = (pos - 1) >> 1
+            pe = self.get(parent)
+            if key(item) <= key(pe):
+                break
+            self.set(pos, pe)
+            pos = parent
+        self.set(pos, item)
+        return ln + 1
+
+    def chase(self, end):
+        ns, kc, s = self.ns, self.kc, self.s
+        chosen = [[ZERO] * 64 for _ in range(kc)]
+        hasl, prefr, pathm = [0] * kc, [0] * kc, [0] * kc
+        for k in range(kc):
+            hl, pr = [False] * 64, [False] * 64
+            for lane in LANES:
+                i = 64 * k + lane
+                cl, cr = 2 * i + 1, 2 * i + 2
+                if ns == 1:
+                    L, R = s[0][cl & 63], s[0][cr & 63]
+                else:
+                    La, Lb = s[2 * k][cl & 63], s[2 * k + 1][cl & 63]
+                    Ra, Rb = s[2 * k][cr & 63], s[2 * k + 1][cr & 63]
+                    L = La if lane < 32 else Lb
+                    R = Ra if lane < 31 else Rb
+                    if 2 * k + 2 < ns and lane == 63:
+                        R = s[2 * k + 2][0]
+                hl[lane] = cl < end
+                pr[lane] = cr < end and key(L) <= key(R)
+                chosen[k][lane] = R if pr[lane] else L
+            hasl[k], prefr[k] = ballot(hl), ballot(pr)
+        pos = 0
+        while True:
+            k, b = pos >> 6, pos & 63
+            if k >= kc:
+                break
+            if not (hasl[k] >> b) & 1:
+                break
+            pathm[k] |= 1 << b
+            pos = 2 * pos + 1 + ((prefr[k] >> b) & 1)
+        return chosen, pathm, pos
+
+    def pop_with_last(self, last, end):
+        root = self.get(0)
+        chosen, pathm, bottom = self.chase(end)
+        J = -1
+        for k in range(self.ns):
+            onpath = []
+            for lane in LANES:
+                i = 64 * k + lane
+                op = i == bottom
+                if k < self.kc:
+                    op = op or (pathm[k] >> lane) & 1 != 0
+                onpath.append(op and i != 0 and key(last) <= key(self.s[k][lane]))
+            m = ballot(onpath)
+            if m:
+                J = 64 * k + highest(m)
+        if J >= 0:
+            new = [list(x) for x in self.s]
+            for k in range(self.kc):
+                for lane in LANES:
+                    i = 64 * k + lane
+                    if (pathm[k] >> lane) & 1 and i < J:
+                        new[k][lane] = chosen[k][lane]
+            self.s = new
+        self.set(J if J >= 0 else 0, last)
+        return root
+
+    def pop(self, ln):
+        last = self.get(ln - 1)
+        ln -= 1
+        if ln == 0:
+            return last, ln
+        return self.pop_with_last(last, ln), ln
+
+    def push_then_pop_full(self, item):
+        cap = self.cap
+        cnt, j = 0, 1
+        while ((cap + 1) >> j) >= 1:
+            if key(item) <= key(self.get(((cap + 1) >> j) - 1)):
+                break
+            cnt = j
+            j += 1
+        last = item
+        if cnt > 0:
+            last = self.get(((cap + 1) >> 1) - 1)
+            for j in range(1, cnt):
+                self.set(((cap + 1) >> j) - 1, self.get(((cap + 1) >> (j + 1)) - 1))
+            self.set(((cap + 1) >> cnt) - 1, item)
+        self.pop_with_last(last, cap)
+
+    def sift_down_range(self, end):
+        elt = self.get(0)
+        chosen, pathm, bottom = self.chase(end)
+        F = -1
+        for k in range(self.ns - 1, -1, -1):
+            onpath = []
+            for lane in LANES:
+                i = 64 * k + lane
+                op = i == bottom
+                if k < self.kc:
+                    op = op or (pathm[k] >> lane) & 1 != 0
+                onpath.append(op and i != 0 and key(elt) >= key(self.s[k][lane]))
+            m = ballot(onpath)
+            if m:
+                F = 64 * k + ctz(m)
+        dest = ((F - 1) >> 1) if F >= 0 else bottom
+        new = [list(x) for x in self.s]
+        for k in range(self.kc):
+            for lane in LANES:
+                i = 64 * k + lane
+                if (pathm[k] >> lane) & 1 and i < dest:
+                    new[k][lane] = chosen[k][lane]
+        self.s = new
+        self.set(dest, elt)
+
+    def array(self, ln):
+        return [self.get(i) for i in range(ln)]
+
+
+@pytest.mark.parametrize("ns", [1, 2, 4])
+@pytest.mark.parametrize("ties", [False, True])
+def test_register_heap_equals_std(ns, ties):
+    """return_points as the search keeps it: pushes up to ef entries, then push + pop for every further one (ef == CAP: the fused
+    form; ef < CAP: push then pop), pops in between, and at the end into_sorted_vec by sift_down_range -- against std."""
+    rnd = random.Random(500 + 10 * ns + ties)
+    k = _keys(rnd, ties)
+    cap = 64 * ns
+    for ef in sorted({1, 2, 3, 7, cap // 2, cap - 2, cap - 1, cap}):
+        if ef < 1:
+            continue
+        for rep in range(6):
+            a, h, ln, t = _StdBinaryHeap(), DevRegHeap(ns), 0, 0
+            for _ in range(rnd.choice([ef, 3 * ef + 5, 600])):
+                r = rnd.random()
+                if ln and r < 0.15:
+                    got, ln = h.pop(ln)
+                    assert a.pop() == got
+                else:
+                    it = (k(), t)
+                    t += 1
+                    if ln == cap:                     # (only when ef == CAP)
+                        a.push(it)
+                        a.pop()
+                        h.push_then_pop_full(it)
+                    else:
+                        a.push(it)
+                        ln = h.push(ln, it)
+                        if ln > ef:
+                            got, ln = h.pop(ln)
+                            assert a.pop() == got
+                assert a.d == h.array(ln), (ns, ef, rep)
+            # into_sorted_vec
+            end = ln
+            d = list(a.d)
+            want = a.into_sorted_vec()
+            while end > 1:
+                end -= 1
+                x, y = h.get(0), h.get(end)
+                h.set(0, y)
+                h.set(end, x)
+                h.sift_down_range(end)
+            assert h.array(ln) == want, (ns, ef, rep, d)
