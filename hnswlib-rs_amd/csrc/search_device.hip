@@ -800,9 +800,21 @@ struct HostCall {
             sink->rows(sink->ctx, answers, lo, hi);
         }
     }
-    static void relax(unsigned& spins) {  // a few ms of busy waiting (the search of a usual batch), then polite polling
-        if (++spins < (1u << 16)) __builtin_ia32_pause();
-        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    // Busy waiting for as long as the search of a usual batch lasts (4 ms by the clock -- a count of `pause` instructions is 1.2 ms
+    // on one CPU and 3 ms on another, and a helper that dozes off just before the answers arrive makes its section end 50-150 us
+    // late: measured, the call went from 1.25 to 1.40 ms whenever the search took a little longer), then polite polling.
+    struct Spin {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        unsigned n = 0;
+        bool napping = false;
+    };
+    static void relax(Spin& w) {
+        if (!w.napping) {
+            __builtin_ia32_pause();
+            if ((++w.n & 255u) == 0u && std::chrono::steady_clock::now() - w.t0 > std::chrono::milliseconds(4)) w.napping = true;
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     }
 };
 }  // namespace
@@ -840,6 +852,7 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     };
     if (sink.begin && !sink.begin(sink.ctx, nq, k)) { err = "out of memory"; return ERR_ARG; }
+    const double us_begin = since(t_begin);
     DirectOut direct{};
     const bool in_place = !want_status && sink.direct && sink.direct(sink.ctx, &direct);
     unsigned char* direct_dev = nullptr;  // the sink's allocation as this device addresses it
@@ -848,6 +861,7 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
         HIP_TRY(hipHostGetDevicePointer(&dp, direct.allocation, 0));
         direct_dev = static_cast<unsigned char*>(dp);
     }
+    const double us_view = since(t_begin) - us_begin;
     auto in_sink = [&](void* host) { return direct_dev + (static_cast<unsigned char*>(host) - static_cast<unsigned char*>(direct.allocation)); };
     const uint64_t q_bytes = nq * d * sizeof(float);
     const uint64_t o_ids = 0, o_dists = o_ids + nq * k * sizeof(uint64_t), o_rank = o_dists + nq * k * sizeof(float),
@@ -898,9 +912,9 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
                      HostCall& h = *static_cast<HostCall*>(ctx);
                      const auto t0 = std::chrono::steady_clock::now();
                      const uint64_t c = lo / h.chunk_rows;
-                     unsigned spins = 0;
+                     HostCall::Spin spin;
                      while (h.chunk_left[c].load(std::memory_order_acquire) != 0)
-                         if (!h.gather_one()) HostCall::relax(spins);
+                         if (!h.gather_one()) HostCall::relax(spin);
                      h.us_gather += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
                  },
                  &hc, hc.chunk_rows};
@@ -932,21 +946,24 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
             }
             return;
         }
-        // a helper: gather tasks while there are any, stay awake while the device searches, unpack
+        // a helper: gather tasks while there are any, stay awake while the device searches (also when there is nothing to unpack:
+        // the next call of a caller that issues call after call then finds it running), unpack
         while (hc.phase.load(std::memory_order_relaxed) == 0 && hc.gather_one()) {}
-        unsigned spins = 0;
+        HostCall::Spin spin;
         int ph;
-        while ((ph = hc.phase.load(std::memory_order_acquire)) == 0) HostCall::relax(spins);
+        while ((ph = hc.phase.load(std::memory_order_acquire)) == 0) HostCall::relax(spin);
         if (ph == 2) hc.unpack_all();
     };
+    const double us_setup = since(t_begin) - us_begin - us_view;
     if (nt == 1) participant(0);
     else WorkerPool::instance().run(nt, nt, participant);
     if (rc != OK) return rc;
     drain.done = true;
     if (trace)
         std::fprintf(stderr, "[hnswgpu host call] %llu queries on %u threads: %.0f us in all; the caller waited %.0f us for gathered chunks, "
-                     "search %.0f us (descent launches included), its share of the unpacking %.0f us\n",
-                     (unsigned long long)nq, nt, since(t_begin), hc.us_gather, us_search, hc.us_unpack);
+                     "search %.0f us (descent launches included), its share of the unpacking %.0f us; before the pool section: sink.begin %.0f us, "
+                     "the sink's memory as the device sees it %.0f us, staging buffers and tasks %.0f us\n",
+                     (unsigned long long)nq, nt, since(t_begin), hc.us_gather, us_search, hc.us_unpack, us_begin, us_view, us_setup);
     return OK;
 }
 

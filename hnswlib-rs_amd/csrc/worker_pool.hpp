@@ -54,7 +54,12 @@ public:
             s.invited = helpers;
             grow_locked(helpers);
         }
-        if (helpers == 1) cv_.notify_one(); else cv_.notify_all();
+        // Wake as many sleepers as there are invitations the lingering (awake) threads will not take -- not all of them: after a
+        // build on every core the pool holds hundreds of threads, and a notify_all per 1.3 ms search call had each of them wake,
+        // queue for the mutex and go back to sleep (~130 us per call, measured through the reference's FFI symbol).  A lingerer
+        // that times out at this very moment leaves its invitation to be withdrawn below: a section never waits for a helper.
+        const unsigned awake = lingering_.load(std::memory_order_relaxed);
+        for (unsigned i = awake; i < helpers; ++i) cv_.notify_one();
         work(s);
         std::exception_ptr err;
         {
@@ -174,6 +179,7 @@ private:
             if (queue_.empty() && linger_us_ > 0) {
                 // stay awake for a moment: the next section of a caller that issues call after call (a batch every ~1.3 ms)
                 // then finds its helpers running instead of paying ~50 us per wake-up
+                lingering_.fetch_add(1, std::memory_order_relaxed);
                 g.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
                 unsigned n = 0;
@@ -184,6 +190,7 @@ private:
                     if ((++n & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(linger_us_)) break;
                 }
                 g.lock();
+                lingering_.fetch_sub(1, std::memory_order_relaxed);
             }
             cv_.wait(g, [this]() { return !queue_.empty(); });
             --idle_;
@@ -208,6 +215,7 @@ private:
     std::deque<Item> queue_;
     unsigned n_threads_ = 0, idle_ = 0, spawning_ = 0;
     std::atomic<unsigned> pending_{0};  // items in queue_ (read without the lock by lingering threads)
+    std::atomic<unsigned> lingering_{0};  // idle threads that are awake, polling pending_
     int linger_us_ = 200;
     const unsigned cap_;
 };
