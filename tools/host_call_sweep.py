@@ -22,12 +22,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="sift1m")
 ap.add_argument("--cache-dir", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_mi355x_bench_cache"))
 ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--build-first", type=int, default=0, help="build (and drop) an index of this many points in the process first, GPU-assisted, "
+                "on every core: what bench.py's process has behind it when it measures the boundary (hundreds of pool threads)")
 ap.add_argument("settings", nargs="*", help="ENV=V[,ENV=V] per setting; the default environment is measured first and last")
 args = ap.parse_args()
 import torch  # noqa: E402
 import hnsw_rs_amd as H  # noqa: E402
 
 cfg = bench.CONFIGS[args.config]
+if args.build_first:
+    hb = H.Hnsw(cfg["M"], args.build_first, 16, cfg["efc"], cfg["dist"])
+    hb.set_build_options(nthreads=0, gpu_device=0, gpu_window=0)
+    hb.parallel_insert(bench.synth(args.build_first, cfg["d"], 0x5EED0009, "clustered"))
+    del hb
 marks = sorted(f for f in glob.glob(os.path.join(args.cache_dir, f"bench_{args.config}_*.done"))
                if len(os.path.basename(f)) == len(f"bench_{args.config}_") + 12 + 5)
 if not marks:
