@@ -92,6 +92,33 @@ int main() {
         stop.store(true);
         busy.join();
     }
+    // 7. a pool that has grown large (a build on every core) and small sections after it, at gaps shorter and longer than the
+    // helpers' lingering time: the section wakes only the sleepers the lingering threads leave work for -- every task still runs
+    // exactly once, helpers still take part (not always: a section never waits for one), and a section of 8 short tasks is not
+    // held up by hundreds of threads waking for nothing
+    {
+        std::atomic<unsigned> grown{0};
+        pool.run(96, 96, [&](unsigned) { grown.fetch_add(1); std::this_thread::sleep_for(std::chrono::milliseconds(2)); });
+        if (grown.load() != 96u) { std::printf("grow: %u of 96 ran\n", grown.load()); return 1; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));  // everyone asleep
+        unsigned helped = 0;
+        for (int round = 0; round < 1500; ++round) {
+            std::vector<int> hit(8, 0);
+            std::mutex m;
+            std::set<std::thread::id> who;
+            pool.run(8, 8, [&](unsigned t) {
+                hit[t] += 1;
+                std::this_thread::sleep_for(std::chrono::microseconds(30));
+                std::lock_guard<std::mutex> g(m);
+                who.insert(std::this_thread::get_id());
+            });
+            for (unsigned t = 0; t < 8; ++t)
+                if (hit[t] != 1) { std::printf("large pool, round %d: task %u ran %d times\n", round, t, hit[t]); return 1; }
+            if (who.size() > 1) ++helped;
+            if (round % 3 == 0) std::this_thread::sleep_for(std::chrono::microseconds(round % 7 == 0 ? 600 : 50));
+        }
+        if (std::thread::hardware_concurrency() >= 4 && helped < 750) { std::printf("large pool: helpers took part in %u of 1500 sections\n", helped); return 1; }
+    }
     std::atomic<unsigned> after{0};
     pool.run(16, 8, [&](unsigned) { after.fetch_add(1); });
     if (after.load() != 16u) { std::printf("after a throwing section: %u != 16\n", after.load()); return 1; }
