@@ -342,6 +342,77 @@ def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, cpu_queries, pct
     return out
 
 
+def live_traffic(args, timeout_s=200):
+    """roofline.traffic measured in THIS invocation, on this box: PMC counters cannot be collected inside a running process, so a
+    short child run of this script (the cached index, strict launches only, nothing else) is put under `rocprofv3 --pmc`, in two
+    passes -- FETCH_SIZE (+ TCC_EA0_RDREQ_sum as a cross-check) and WRITE_SIZE do not fit one pass, and counters are never mixed
+    with trace domains -- and the counters are averaged per dispatch of the strict search kernel in the default arithmetic.
+    Corrected as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE is in KB and, on gfx950, counts 128-byte requests at
+    64 bytes: bytes = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (fabric side: Infinity-Cache hits included).  Returns
+    (bytes per launch or None, details)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return None, {"skipped": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, {"skipped": "this process is itself being profiled (rocprofv3 environment found): no nested counter runs"}
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", args.config, "--data", args.data, "--steps", "3", "--warmup", "1",
+             "--cache-dir", args.cache_dir, "--batches", str(args.batches), "--no-cpu-baseline", "--no-recall", "--no-concurrent",
+             "--no-boundary", "--no-traffic"]
+    if args.n:
+        child += ["--n", str(args.n)]
+    if args.nq:
+        child += ["--nq", str(args.nq)]
+    if args.ef:
+        child += ["--ef", str(args.ef)]
+    out = tempfile.mkdtemp(prefix="hnsw_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("HNSW_BENCH_ARGV", None)
+    counters = {}
+    try:
+        for name, ctrs in (("fetch", ["FETCH_SIZE", "TCC_EA0_RDREQ_sum"]), ("write", ["WRITE_SIZE"])):
+            r = subprocess.run([tool, "--pmc", *ctrs, "-d", os.path.join(out, name), "--output-format", "csv", "--", *child],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, {"skipped": f"rocprofv3 --pmc {' '.join(ctrs)} exited with {r.returncode}: {(r.stderr or '')[-300:]}"}
+            per = {}
+            for f in glob.glob(os.path.join(out, name, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    kn = row["Kernel_Name"]
+                    i = kn.find("hnsw_search_kernel<")
+                    if i < 0:
+                        continue
+                    targs = kn[i + len("hnsw_search_kernel<"):].split(">")[0].split(",")
+                    if targs[-1].strip() != "true" or int(targs[0]) >= 7:   # strict launches in the default (scalar-order) arithmetic
+                        continue
+                    key = (f, row["Dispatch_Id"], row["Counter_Name"])
+                    per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            for (_f, _d, c), v in per.items():
+                counters.setdefault(c, []).append(v)
+    except subprocess.TimeoutExpired:
+        return None, {"skipped": f"a rocprofv3 --pmc pass did not finish in {timeout_s} s"}
+    except Exception as e:  # noqa: BLE001 -- an informational figure: never at the expense of the line
+        return None, {"skipped": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    if not counters.get("FETCH_SIZE") or not counters.get("WRITE_SIZE"):
+        return None, {"skipped": "no dispatch of the strict search kernel in the counter output"}
+    avg = {c: float(np.mean(v)) for c, v in counters.items()}
+    nbytes = int(avg["FETCH_SIZE"] * 1024 * 2 + avg["WRITE_SIZE"] * 1024)
+    return nbytes, {"FETCH_SIZE_KB": round(avg["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(avg["WRITE_SIZE"], 1),
+                    "TCC_EA0_RDREQ": round(avg.get("TCC_EA0_RDREQ_sum", float("nan")), 1),
+                    "fetch_bytes_from_rdreq_x128": int(avg["TCC_EA0_RDREQ_sum"] * 128) if "TCC_EA0_RDREQ_sum" in avg else None,
+                    "dispatches_averaged": {c: len(v) for c, v in counters.items()},
+                    "how": "this invocation, this box: two `rocprofv3 --pmc` passes (FETCH_SIZE TCC_EA0_RDREQ_sum | WRITE_SIZE) over a child run "
+                           "`bench.py --steps 3 --warmup 1` (same config, cached index, all 4 query batches), per dispatch of the strict "
+                           "search kernel; bytes = FETCH_SIZE (KB) x 1024 x 2 (gfx950: 128-byte requests tallied at 64) + WRITE_SIZE (KB) x 1024; "
+                           "fabric-side requests, Infinity-Cache hits included"}
+
+
 def boundary_timings(H, lib, index, cache_dir, base, dist_name, Q, k, ef, n, reps=25):
     """What a caller pays above the device-buffer call (reported next to `value`, never as `value`):
     * host_buffers: hnswgpu_search_batch -- pageable host matrices in, host arrays out (the queries read across PCIe by the descent
@@ -410,6 +481,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the two-caller-threads reference measurement")
     ap.add_argument("--no-recall", action="store_true", help="skip the brute-force ground truth (quick A/B runs)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs behind roofline.traffic (N = 1 only; ~1 minute)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the timings of the host-buffer / reference-FFI / filtered entry points")
     ap.add_argument("--dump-stats", default="", help="write the per-query kernel stats of the last step to this .npy")
     ap.add_argument("--dump-answers", default="", help="write the answers of batch 0 (all ranks' shards gathered, input order) to this .npz")
@@ -775,8 +847,8 @@ def main():
     all_st = np.concatenate(batch_stats)
     roofline = {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # PMC counters cannot be collected inside this process: `traffic` stays null here; the rocprofv3 --pmc
-                # measurement of the same command is quoted from the committed profile, with its file name
+                # PMC counters cannot be collected inside this process: `traffic` is filled in below from two rocprofv3 --pmc
+                # child runs (live_traffic; N = 1), and the committed profile of an earlier box is quoted beside it
                 "traffic": None, "traffic_from_profile": traffic_profile,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
                 "all_kernels_ms": round(all_ms, 4),
@@ -833,11 +905,22 @@ def main():
             "simd_order_queries_per_s": None if simd_qps is None else round(simd_qps, 1),
             "two_caller_threads_queries_per_s": None if two_callers_qps is None else round(two_callers_qps, 1),
             "boundary": boundary,
-            "roofline": roofline,
+            "roofline": roofline,  # (+ traffic, below)
             "cpu_baseline": cpu_baseline,
             "parity_vs_oracle": parity,
             "setup_s": {"build": round(t_build, 1), "load_upload": round(t_load, 1)},
         }
+        if world == 1 and not args.no_traffic:
+            # last, so that nothing of it can disturb what was measured above: the device is idle, this process only waits
+            t0 = time.time()
+            nbytes, detail = live_traffic(args)
+            detail["seconds"] = round(time.time() - t0, 1)
+            roofline["traffic"] = nbytes
+            roofline["traffic_unit"] = "bytes per launch (like algorithmic_bytes_per_launch)"
+            roofline["traffic_live"] = detail
+            if nbytes:
+                roofline["traffic_over_algorithmic"] = round(nbytes / roofline["algorithmic_bytes_per_launch"], 3)
+            log(f"roofline.traffic: {nbytes} bytes per launch ({detail.get('seconds')} s)" if nbytes else f"roofline.traffic skipped: {detail.get('skipped')}")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist_pg.barrier()

@@ -35,7 +35,7 @@ case "$EXP" in
     run() {
       local tag=$1; shift
       echo "== $CFG $tag"
-      env HNSWGPU_TRACE_LAUNCH=1 "$@" timeout 400 python bench.py --config $CFG --steps 12 --warmup 3 --no-recall --no-boundary --no-cpu-baseline \
+      env HNSWGPU_TRACE_LAUNCH=1 "$@" timeout 400 python bench.py --config $CFG --steps 12 --warmup 3 --no-recall --no-boundary --no-cpu-baseline --no-traffic \
           --dump-stats gpurun_out/$TAG/st_$tag.npy 2> gpurun_out/$TAG/err_$tag.log | tee gpurun_out/$TAG/bench_$tag.json | line | cut -c1-220
       grep "hnswgpu launch" gpurun_out/$TAG/err_$tag.log | sort | uniq -c | sort -rn | head -2
     }
@@ -78,7 +78,7 @@ PY
       grep -E "built in" $O/bench_$cfg.log
     done
     stamp "config 4's batch on one GPU (100 000 queries per call)"
-    timeout 600 python bench.py --config sift1m --nq 100000 --steps 5 --warmup 2 --no-boundary > $O/bench_sift1m_nq100k.json 2> $O/bench_sift1m_nq100k.log
+    timeout 600 python bench.py --config sift1m --nq 100000 --steps 5 --warmup 2 --no-boundary --no-traffic > $O/bench_sift1m_nq100k.json 2> $O/bench_sift1m_nq100k.log
     line < $O/bench_sift1m_nq100k.json
     stamp "N = 2 as a plain command (both ranks on the one device)"
     timeout 400 python bench.py --gpus 2 --share-device --backend nccl --nq 5000 --steps 10 --warmup 2 --no-cpu-baseline --no-recall \

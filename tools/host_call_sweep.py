@@ -2,7 +2,7 @@
 """The host-buffer boundary of one config under several settings of the library's tuning hooks, in ONE process on ONE index (graphs
 differ per box): hnswgpu_search_batch with output arrays that are reused (what a caller in steady state does -- fresh numpy arrays
 take a page fault per 4 KB while the answers are unpacked), the reference's FFI symbol, and the device-resident call beside them.
-    python bench.py --config sift1m --steps 2 --warmup 1 --no-boundary --no-cpu-baseline --no-recall   # builds and caches the index
+    python bench.py --config sift1m --steps 2 --warmup 1 --no-boundary --no-cpu-baseline --no-recall --no-traffic   # builds and caches the index
     python tools/host_call_sweep.py --config sift1m "HNSWGPU_HOST_THREADS=16" "HNSWGPU_HOST_THREADS=16,HNSWGPU_HOST_CHUNKS=8"
 """
 import argparse

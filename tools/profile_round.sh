@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$1; shift
 mkdir -p $O
-B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-recall --no-concurrent --no-boundary $*"
+B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-recall --no-concurrent --no-boundary --no-traffic $*"
 rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- $B > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum -d $O/pmc_fetch --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- $B > /dev/null 2>&1
