@@ -342,7 +342,7 @@ def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, cpu_queries, pct
     return out
 
 
-def live_traffic(args, timeout_s=200):
+def live_traffic(args, timeout_s=120):
     """roofline.traffic measured in THIS invocation, on this box: PMC counters cannot be collected inside a running process, so a
     short child run of this script (the cached index, strict launches only, nothing else) is put under `rocprofv3 --pmc`, in two
     passes -- FETCH_SIZE (+ TCC_EA0_RDREQ_sum as a cross-check) and WRITE_SIZE do not fit one pass, and counters are never mixed
