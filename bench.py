@@ -488,6 +488,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (gloo only to exercise the multi-rank path on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (1-GPU box test of the N>1 path)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N = 1 only: run the N > 1 exchange anyway -- a ONE-rank process group of --backend (nccl = RCCL) and the same "
+                         "overlapped packed all-gather per step -- so that the RCCL path is exercised on a 1-GPU box (rehearsal of the 8-GPU run)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the steps rotate through (a step that "
                     "re-searches the batch of the previous step finds its rows in the 256 MiB Infinity Cache)")
@@ -515,10 +518,19 @@ def main():
     dist_pg = None
     rccl = None
     backend_used = args.backend
-    if world > 1:
+    pg = world > 1 or args.exchange  # a process group exists and every step ends with the exchange of the packed answers
+    if pg:
         import datetime
         import torch.distributed as dist_pg_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:  # --exchange without a launcher: a rendezvous of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         fallback_reason = os.environ.get("HNSW_BENCH_GATHER_FALLBACK") if args.share_device else None
         if args.backend == "nccl" and fallback_reason is None:
             # backend "nccl" IS RCCL on ROCm; the communicator is created here (device_id)
@@ -529,7 +541,7 @@ def main():
             dist_pg_mod.init_process_group("gloo", timeout=datetime.timedelta(hours=2))
         dist_pg = dist_pg_mod
     coll_dev = dev if backend_used == "nccl" else torch.device("cpu")  # gloo collectives run on host tensors
-    if world > 1:
+    if pg:
         seen = torch.ones(1, dtype=torch.int64, device=coll_dev)
         dist_pg.all_reduce(seen)  # every rank of the group adds one: the ranks this communicator really spans
         try:
@@ -601,7 +613,7 @@ def main():
     # has been waited for, and the timed region ends with every exchange complete (hnsw_rs_amd.sharded.OverlappedExchange;
     # CPU-tested over gloo in tests/test_sharding.py)
     from hnsw_rs_amd.sharded import OverlappedExchange, PackedAnswers
-    xch = OverlappedExchange(nq_total, k, world, dev, coll_dev) if world > 1 else None
+    xch = OverlappedExchange(nq_total, k, world, dev, coll_dev) if pg else None
     packed = xch.packs[0] if xch else PackedAnswers(nq_local, k, dev)
     out_ids, out_dists, out_counts = packed.ids, packed.dists, packed.counts
     out_layer = torch.zeros((nq_local, k), dtype=torch.uint8, device=dev)
@@ -627,7 +639,7 @@ def main():
         ms, _ = index.last_kernel_ms()  # HIP events on the launch stream, inside the library
         kernel_ms.append(ms)
         main_ms.append(index.last_search_kernel_ms())
-        if world > 1 and exchange:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
+        if pg and exchange:  # the only exchange on this path: ONE all-gather of the packed answers (RCCL over xGMI)
             t0 = time.perf_counter()
             xch.exchange(i, overlap)
             if not overlap:  # (measured alone: what an exchange costs when nothing hides it)
@@ -637,7 +649,7 @@ def main():
 
     def fence():
         drain_exchanges()
-        if world > 1:
+        if pg:
             dist_pg.barrier()
         torch.cuda.synchronize(dev)
 
@@ -648,7 +660,7 @@ def main():
             step(i)
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if pg:
             t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist_pg.all_reduce(t, op=dist_pg.ReduceOp.MAX)
             el = float(t.item())
@@ -675,7 +687,7 @@ def main():
     timed_main_ms = list(main_ms)
     timed_kernel_ms = list(kernel_ms)
     gather_ms = None
-    if world > 1:  # untimed: a few steps with the exchange NOT overlapped and waited for, to say what one costs by itself
+    if pg:  # untimed: a few steps with the exchange NOT overlapped and waited for, to say what one costs by itself
         gather_marks.clear()
         for i in range(4):
             step(i, overlap=False)
@@ -774,7 +786,7 @@ def main():
     step(0)   # leave the strict answers of batch 0 in the output buffers for the recall / parity checks below
     fence()
     if args.dump_answers and rank == 0:  # batch 0 in input order: what the caller of parallel_search gets back
-        if world > 1:
+        if pg:  # (what came back through the collective, not this rank's send buffer)
             g_ids, g_dists, g_counts = xch.gathered(0)
             np.savez(args.dump_answers, ids=g_ids.cpu().numpy(), dists=g_dists.cpu().numpy(), counts=g_counts.cpu().numpy())
         else:
@@ -895,7 +907,7 @@ def main():
                        "queries_total": nq_total, "graph": "replicated per GPU",
                        "exchange": ("one all_gather_into_tensor per step of the packed answers (ids | distances | counts, %d bytes per rank) over %s, "
                                     "issued asynchronously: it overlaps the search of the next step (two answer buffers alternate); the timed "
-                                    "region ends with every exchange complete" % (xch.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
+                                    "region ends with every exchange complete" % (xch.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if pg else "none",
                        "parallelism": f"{world} x (replica + {nq_local} queries)"},
             "rccl": rccl,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
@@ -922,7 +934,7 @@ def main():
                 roofline["traffic_over_algorithmic"] = round(nbytes / roofline["algorithmic_bytes_per_launch"], 3)
             log(f"roofline.traffic: {nbytes} bytes per launch ({detail.get('seconds')} s)" if nbytes else f"roofline.traffic skipped: {detail.get('skipped')}")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg:
         dist_pg.barrier()
         dist_pg.destroy_process_group()
 

@@ -587,6 +587,27 @@ int hnswgpu_search_batch_sharded_device(const hnswgpu_index* cidx, const int* de
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
 }
 
+int hnswgpu_gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_shard, uint64_t k,
+                                   const uint64_t* const* d_ids, const float* const* d_dists, const uint8_t* const* d_layer,
+                                   const int32_t* const* d_rank, const uint32_t* const* d_counts, int root_device,
+                                   uint64_t* root_ids, float* root_dists, uint8_t* root_layer, int32_t* root_rank,
+                                   uint32_t* root_counts, void* root_stream) {
+    CAPI_GUARD_BEGIN
+    if (!devices || n_shards <= 0 || !nq_shard || !d_ids || !d_dists || !d_counts || k == 0) return fail(HNSWGPU_ERR_ARG, "bad argument");
+    uint64_t total = 0;
+    for (int s = 0; s < n_shards; ++s) {
+        if (nq_shard[s] && (!d_ids[s] || !d_dists[s] || !d_counts[s])) return fail(HNSWGPU_ERR_ARG, "null buffer");
+        total += nq_shard[s];
+    }
+    if (total && (!root_ids || !root_dists || !root_counts)) return fail(HNSWGPU_ERR_ARG, "null buffer");
+    std::string err;
+    int rc = hnswgpu::gather_sharded_answers(devices, n_shards, nq_shard, k, d_ids, d_dists, d_layer, d_rank, d_counts, root_device,
+                                             root_ids, root_dists, root_layer, root_rank, root_counts, root_stream, err);
+    if (rc != OK) return fail(rc, err);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
 static int search_device_common(const hnswgpu_index* cidx, const float* d_queries, uint64_t nq, uint64_t d, uint64_t k, uint64_t ef,
                                 const uint64_t* d_allowed, uint64_t n_allowed, uint64_t* d_out_ids, float* d_out_dists,
                                 uint8_t* d_out_layer, int32_t* d_out_rank, uint32_t* d_out_counts, uint32_t* d_stats, void* stream,

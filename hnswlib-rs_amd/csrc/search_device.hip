@@ -247,6 +247,31 @@ int device_count() {
     return n;
 }
 
+int gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_shard, uint64_t k, const uint64_t* const* d_ids,
+                           const float* const* d_dists, const uint8_t* const* d_layer, const int32_t* const* d_rank,
+                           const uint32_t* const* d_counts, int root_device, uint64_t* root_ids, float* root_dists,
+                           uint8_t* root_layer, int32_t* root_rank, uint32_t* root_counts, void* root_stream, std::string& err) {
+    DeviceGuard on_root(root_device);
+    HIP_TRY(on_root.status());
+    hipStream_t stream = static_cast<hipStream_t>(root_stream);
+    uint64_t row = 0;  // first query of shard s in input order
+    for (int s = 0; s < n_shards; ++s) {
+        const uint64_t cnt = nq_shard[s];
+        if (cnt == 0) continue;
+        const int src = devices[s];
+        HIP_TRY(hipMemcpyPeerAsync(root_ids + row * k, root_device, d_ids[s], src, cnt * k * sizeof(uint64_t), stream));
+        HIP_TRY(hipMemcpyPeerAsync(root_dists + row * k, root_device, d_dists[s], src, cnt * k * sizeof(float), stream));
+        if (root_layer && d_layer && d_layer[s])
+            HIP_TRY(hipMemcpyPeerAsync(root_layer + row * k, root_device, d_layer[s], src, cnt * k * sizeof(uint8_t), stream));
+        if (root_rank && d_rank && d_rank[s])
+            HIP_TRY(hipMemcpyPeerAsync(root_rank + row * k, root_device, d_rank[s], src, cnt * k * sizeof(int32_t), stream));
+        HIP_TRY(hipMemcpyPeerAsync(root_counts + row, root_device, d_counts[s], src, cnt * sizeof(uint32_t), stream));
+        row += cnt;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return OK;
+}
+
 DeviceIndex::DeviceIndex() = default;
 DeviceIndex::~DeviceIndex() { release(); }
 

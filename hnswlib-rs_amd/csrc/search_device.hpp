@@ -177,6 +177,14 @@ private:
 };
 
 int device_count();
+// The gather of a sharded search without any collective library: shard s's answers (nq_shard[s] x k, resident on
+// devices[s]) are copied behind one another -- input order -- into the arrays of `root_device` with hipMemcpyPeerAsync on
+// `root_stream` (xGMI between the GPUs of a node, a device-to-device copy when a shard lives on the root), then the stream is
+// waited for.  layer / rank arrays and their per-shard entries may be null.
+int gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_shard, uint64_t k, const uint64_t* const* d_ids,
+                           const float* const* d_dists, const uint8_t* const* d_layer, const int32_t* const* d_rank,
+                           const uint32_t* const* d_counts, int root_device, uint64_t* root_ids, float* root_dists,
+                           uint8_t* root_layer, int32_t* root_rank, uint32_t* root_counts, void* root_stream, std::string& err);
 // the device side of GPU-assisted construction (builder.hpp) on HIP device `device`
 std::unique_ptr<BuildSearchBackend> make_device_build_backend(int device);
 // Distance<f32>::eval on the device through the search kernel's own distance routine: out[q][r] = dist(queries[q],

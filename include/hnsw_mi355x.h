@@ -205,6 +205,16 @@ int hnswgpu_search_batch_sharded_device(const hnswgpu_index* idx, const int* dev
                                         const uint64_t* nq_shard, uint64_t d, uint64_t k, uint64_t ef, uint64_t* const* d_out_ids,
                                         float* const* d_out_dists, uint8_t* const* d_out_layer, int32_t* const* d_out_rank,
                                         uint32_t* const* d_out_counts, void* const* streams);
+/* The exchange that follows hnswgpu_search_batch_sharded_device when ONE process drives the node's GPUs and holds no collective
+ * library (a Rust host): shard s's answers (nq_shard[s] x k on devices[s]) are copied behind one another -- input order, the order
+ * Hnsw::parallel_search returns (src/hnsw.rs:1623-1633) -- into the arrays of root_device with hipMemcpyPeerAsync on root_stream
+ * (xGMI between the GPUs of a node), and the stream is waited for.  1.2-1.7 MB per shard at BASELINE config 4.  d_layer / d_rank,
+ * their entries and root_layer / root_rank may be NULL.                                                                       */
+int hnswgpu_gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_shard, uint64_t k,
+                                   const uint64_t* const* d_ids, const float* const* d_dists, const uint8_t* const* d_layer,
+                                   const int32_t* const* d_rank, const uint32_t* const* d_counts, int root_device,
+                                   uint64_t* root_ids, float* root_dists, uint8_t* root_layer, int32_t* root_rank,
+                                   uint32_t* root_counts, void* root_stream);
 
 /* Same with every buffer already resident in HBM (device pointers), launched on HIP stream
  * `stream` (hipStream_t as void*; NULL = default stream).  Synchronises `stream` once

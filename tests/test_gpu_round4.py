@@ -84,6 +84,20 @@ def test_config4_100k_queries_in_8_shards_on_1m_x_128(native, oracle, sift1m):
     ref = o.parallel_search(Q, k, ef)
     assert_same(got, ref)
     print(f"config 4: 100 000 queries in 8 shards over {ndev} device(s) {sorted(set(devs))}: all answers == oracle")
+    # the gather without a collective library (a Rust host driving the node's GPUs from one process): peer copies into device 0
+    root = torch.device("cuda", 0)
+    g_ids = torch.zeros((nq, k), dtype=torch.int64, device=root)
+    g_d = torch.zeros((nq, k), dtype=torch.float32, device=root)
+    g_l = torch.zeros((nq, k), dtype=torch.uint8, device=root)
+    g_r = torch.zeros((nq, k), dtype=torch.int32, device=root)
+    g_c = torch.zeros((nq,), dtype=torch.int32, device=root)
+    torch.cuda.synchronize(0)
+    rc = lib.hnswgpu_gather_sharded_answers((C.c_int * n_sh)(*devs), n_sh, (C.c_uint64 * n_sh)(*sizes), k, ptrs(ids), ptrs(dists), ptrs(layers),
+                                            ptrs(ranks), ptrs(counts), 0, g_ids.data_ptr(), g_d.data_ptr(), g_l.data_ptr(), g_r.data_ptr(),
+                                            g_c.data_ptr(), None)
+    assert rc == 0, native._native.last_error()
+    assert_same(oracle.SearchResult(g_ids.cpu().numpy().astype(np.uint64), g_d.cpu().numpy(), g_l.cpu().numpy(), g_r.cpu().numpy(),
+                                    g_c.cpu().numpy().astype(np.uint32)), ref)
     # one call, one device, the whole batch (the large-batch end of hnswgpu_search_batch)
     assert_same(h.parallel_search_flat(Q, k, ef), ref)
     assert h.last_tie_count() > 0
