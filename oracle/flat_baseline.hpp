@@ -8,6 +8,7 @@
 // TEST INFRASTRUCTURE / bench.py's cpu_baseline leg only (timing and recall sanity).  Its sums differ from the scalar
 // reference order in the last bits, so it is never used for a parity check.
 #pragma once
+#include "pinning.hpp"
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -135,7 +136,8 @@ struct FlatBaseline {
         if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
         if (nthreads < 1) nthreads = 1;
         std::atomic<size_t> next{0};
-        auto worker = [&]() {
+        auto worker = [&](int t) {
+            oracle_pin::Pin on_cpu(t);
             Scratch s;
             for (;;) {
                 const size_t i0 = next.fetch_add(16);
@@ -145,8 +147,8 @@ struct FlatBaseline {
             }
         };
         std::vector<std::thread> th;
-        for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
-        worker();
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
+        worker(0);
         for (auto& t : th) t.join();
     }
 };

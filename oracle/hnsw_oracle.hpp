@@ -18,6 +18,7 @@
 //
 // Reference citations are relative to /root/reference.
 #pragma once
+#include "pinning.hpp"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -559,6 +560,7 @@ public:
         std::atomic<size_t> next{0};
         std::vector<Counters> cnts(nthreads);
         auto worker = [&](int t) {
+            oracle_pin::Pin on_cpu(t);  // (orc_set_thread_pinning: worker t on the t-th CPU, node by node; off by default)
             for (;;) {
                 size_t i = next.fetch_add(1);
                 if (i >= nq) break;

@@ -73,6 +73,14 @@ int orc_search(void* hv, const float* q, size_t d, size_t k, size_t ef, uint64_t
 // parallel_search call itself is timed (*elapsed_s), like
 // examples/ann-sift1m-128-euclidean.rs:148-164.  counters (may be null) = {n_dist, n_expand,
 // n_ids_read} summed over all queries.
+// placement of the worker threads of every parallel_search of this library: 0 = wherever the scheduler puts them (default),
+// 1 = worker t pinned to the t-th logical CPU, NUMA node by NUMA node (pinning.hpp)
+void orc_set_thread_pinning(int mode) { oracle_pin::mode().store(mode); }
+int orc_pinning_cpu(int t) {
+    const std::vector<int>& o = oracle_pin::cpu_order();
+    return o.empty() ? -1 : o[(size_t)t % o.size()];
+}
+
 int orc_parallel_search(void* hv, const float* queries, size_t nq, size_t d, size_t k, size_t ef, int nthreads,
                         uint64_t* out_ids, float* out_dists, uint8_t* out_layer, int32_t* out_rank,
                         uint32_t* out_counts, uint64_t* counters, double* elapsed_s) {

@@ -227,6 +227,16 @@ class OracleHnsw:
         """The optimised flat-array CPU searcher built from this index (timing only: see oracle/flat_baseline.hpp)."""
         return FlatBaseline(self)
 
+    @staticmethod
+    def set_thread_pinning(on):
+        """Timing-only: worker t of every parallel_search runs on the t-th logical CPU, NUMA node by NUMA node (oracle/pinning.hpp)."""
+        lib().orc_set_thread_pinning(int(bool(on)))
+
+    @staticmethod
+    def pinning_cpu(t):
+        lib().orc_pinning_cpu.restype = C.c_int
+        return int(lib().orc_pinning_cpu(int(t)))
+
     def set_simd_order(self, on):
         """Timing-only: distances summed in the crate's SIMD (8-lane) order; results differ in the last bits."""
         lib().orc_set_simd_order(C.c_void_p(self.h), int(bool(on)))
