@@ -587,6 +587,17 @@ int hnswgpu_search_batch_sharded_device(const hnswgpu_index* cidx, const int* de
     CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
 }
 
+int hnswgpu_lane_lab(int device, uint32_t mode, uint32_t p0, uint32_t p1, uint32_t p2, const uint32_t* ops, uint32_t n_ops,
+                     const uint32_t* lanes, uint32_t n_lane_sets, uint32_t* out, uint32_t out_words) {
+    CAPI_GUARD_BEGIN
+    if ((n_ops && !ops) || (n_lane_sets && !lanes) || !out) return fail(HNSWGPU_ERR_ARG, "null buffer");
+    std::string err;
+    int rc = lane_lab_device(device, mode, p0, p1, p2, ops, n_ops, lanes, n_lane_sets, out, out_words, err);
+    if (rc != OK) return fail(rc, err);
+    return HNSWGPU_OK;
+    CAPI_GUARD_END(HNSWGPU_ERR_DEVICE)
+}
+
 int hnswgpu_gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_shard, uint64_t k,
                                    const uint64_t* const* d_ids, const float* const* d_dists, const uint8_t* const* d_layer,
                                    const int32_t* const* d_rank, const uint32_t* const* d_counts, int root_device,

@@ -247,6 +247,40 @@ int device_count() {
     return n;
 }
 
+int lane_lab_device(int device, uint32_t mode, uint32_t p0, uint32_t p1, uint32_t p2, const uint32_t* ops, uint32_t n_ops,
+                    const uint32_t* lanes, uint32_t n_lane_sets, uint32_t* out, uint32_t out_words, std::string& err) {
+    if (mode > 3u || out_words < 1u) { err = "bad lane-lab mode"; return ERR_ARG; }
+    if (mode == 0u && p0 > 1024u) { err = "lane lab: at most 1024 heap entries in LDS"; return ERR_ARG; }
+    if ((mode == 1u || mode == 2u) && p0 != 1u && p0 != 2u && p0 != 4u) { err = "lane lab: 1, 2 or 4 slots per lane"; return ERR_ARG; }
+    if (mode == 2u && (p1 == 0u || p1 > 64u * p0)) { err = "lane lab: ef beyond the result set"; return ERR_ARG; }
+    if (mode == 3u && (p0 < 4u || p0 > 12u || p2 > 13u || p1 > 31u || p1 + 3u < p0 || p1 - (p0 - 3u) != p2)) { err = "lane lab: table geometry"; return ERR_ARG; }
+    DeviceGuard on_device(device);
+    HIP_TRY(on_device.status());
+    const uint32_t scratch_cap = 1u << 16;
+    DevBuf d_ops, d_lanes, d_out, d_scratch;
+    struct Free { DevBuf* b[4]; ~Free() { for (DevBuf* x : b) x->free(); } } fr{{&d_ops, &d_lanes, &d_out, &d_scratch}};
+    HIP_TRY(d_ops.ensure(std::max<uint64_t>(16, (uint64_t)n_ops * 16)));
+    HIP_TRY(d_lanes.ensure(std::max<uint64_t>(512, (uint64_t)n_lane_sets * 512)));
+    HIP_TRY(d_out.ensure((uint64_t)out_words * 4));
+    HIP_TRY(d_scratch.ensure((uint64_t)scratch_cap * sizeof(hent_t)));
+    if (n_ops) HIP_TRY(hipMemcpy(d_ops.p, ops, (size_t)n_ops * 16, hipMemcpyHostToDevice));
+    if (n_lane_sets) HIP_TRY(hipMemcpy(d_lanes.p, lanes, (size_t)n_lane_sets * 512, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out.p, 0, (size_t)out_words * 4));
+    LaneLabArgs a{};
+    a.ops = d_ops.as<uint32_t>();
+    a.n_ops = n_ops;
+    a.lanes = d_lanes.as<uint32_t>();
+    a.mode = mode; a.p0 = p0; a.p1 = p1; a.p2 = p2;
+    a.scratch = d_scratch.as<hent_t>();
+    a.scratch_cap = scratch_cap;
+    a.out = d_out.as<uint32_t>();
+    a.out_cap = out_words;
+    HIP_TRY(launch_lane_lab(nullptr, 16384, a));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)out_words * 4, hipMemcpyDeviceToHost));
+    return OK;
+}
+
 int gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_shard, uint64_t k, const uint64_t* const* d_ids,
                            const float* const* d_dists, const uint8_t* const* d_layer, const int32_t* const* d_rank,
                            const uint32_t* const* d_counts, int root_device, uint64_t* root_ids, float* root_dists,

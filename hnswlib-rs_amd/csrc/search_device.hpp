@@ -193,4 +193,9 @@ std::unique_ptr<BuildSearchBackend> make_device_build_backend(int device);
 int eval_distance_matrix_device(int dist, const float* queries, uint64_t nq, const float* rows, uint64_t n, uint64_t d,
                                 uint32_t nf, bool pairs, float* out, std::string& err, int arithmetic = 0);
 
+// The lane lab (search_kernels.hpp, lane_lab.inc): runs a script of wave-level operations of the search kernels on `device`
+// (host buffers in, host buffer out; out[0] = words produced).  Test entry.
+int lane_lab_device(int device, uint32_t mode, uint32_t p0, uint32_t p1, uint32_t p2, const uint32_t* ops, uint32_t n_ops,
+                    const uint32_t* lanes, uint32_t n_lane_sets, uint32_t* out, uint32_t out_words, std::string& err);
+
 }  // namespace hnswgpu

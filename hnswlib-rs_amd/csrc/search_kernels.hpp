@@ -145,6 +145,21 @@ struct SelectArgs {
     uint32_t* work_counter;
 };
 
+// The lane lab (lane_lab.inc, hnswgpu_lane_lab): a script of wave-level operations run by one wavefront, for the tests
+constexpr uint32_t LAB_PUSH = 1, LAB_POP = 2, LAB_PUSH_LANES = 3, LAB_INSERT = 4, LAB_MERGE = 5, LAB_BATCH = 6, LAB_VISIT = 7;
+struct LaneLabArgs {
+    const uint32_t* ops;    // [n_ops][4] = {op, a, b, c}
+    uint32_t n_ops;
+    const uint32_t* lanes;  // [n_sets][64][2] = {f32 bits, id}: the lane vectors (de / idc) of LAB_PUSH_LANES / LAB_MERGE / LAB_BATCH
+    uint32_t mode;          // 0 memory heap, 1 register heap, 2 result set, 3 visited table
+    uint32_t p0, p1, p2;    // mode 0: LDS entries, pop variant; 1: slots per lane; 2: slots per lane, ef; 3: tbits, idbits, restbits
+    hent_t* scratch;        // mode 0: the heap's global slice
+    uint32_t scratch_cap;
+    uint32_t* out;          // out[0] = words produced (itself included), then the results in script order, then the final state
+    uint32_t out_cap;
+};
+hipError_t launch_lane_lab(hipStream_t stream, size_t lds, const LaneLabArgs& a);
+
 // Three translation units per metric instantiate the kernels (search_kernels_tu.hip with -DHNSW_THIS_METRIC / -DHNSW_PART:
 // strict search kernels, lean search kernels, everything else) -- keeps the build parallel and the objects small.
 struct KernelSet {

@@ -297,6 +297,18 @@ int hnswgpu_eval_distance_matrix(int dist, const float* queries, uint64_t nq, co
 int hnswgpu_eval_distance_matrix_arith(int dist, int arithmetic, const float* queries, uint64_t nq, const float* rows,
                                        uint64_t n, uint64_t d, uint32_t batch, float* out);
 
+/* Test entry: the lane lab.  The wave-level algorithms the search kernels are made of -- the reference's BinaryHeap (src/hnsw.rs:940,
+ * :958-973, :1035-1053, :1544; std's push / pop / into_sorted_vec) as a memory heap and as a register heap, the sorted result set
+ * with its accept rule (:1028-1053), the exact visited table (:955-956, :1016-1017) -- run on `device` by ONE wavefront from a
+ * script: ops[n_ops][4] = {op, a, b, c}, lanes[n_lane_sets][64][2] = {f32 bits, id} (the lane vectors of the batch operations).
+ * mode 0 memory heap (p0 entries in LDS, p1 pop variant), 1 register heap (p0 slots per lane), 2 result set (p0 slots per lane,
+ * p1 ef), 3 visited table (p0 tbits, p1 idbits, p2 restbits).  out[0] = words produced, then every operation's result in script
+ * order, then the final state.  Operation codes and layouts: hnswlib-rs_amd/csrc/search_kernels.hpp (LAB_*), lane_lab.inc;
+ * tests/test_gpu_lane_lab.py drives it.                                                                                    */
+int hnswgpu_lane_lab(int device, uint32_t mode, uint32_t p0, uint32_t p1, uint32_t p2, const uint32_t* ops, uint32_t n_ops,
+                     const uint32_t* lanes, uint32_t n_lane_sets, uint32_t* out, uint32_t out_words);
+
+
 /* =======================================================================================
  * (2) The reference's own C ABI for f32 (src/libext.rs), same names and struct layouts.
  * ======================================================================================= */
