@@ -166,7 +166,7 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     arithmetic = "scalar (bit-exact order)"
     if simd_trials[simd_threads] > cpu_qps:
         cpu_qps, best_threads, placement = simd_trials[simd_threads], simd_threads, "pinned"
-        arithmetic = "simd-order (8 f32 lanes, the crate's simdeez_f build)"
+        arithmetic = "approximate simd-order (8 vertical f32 lanes summed left to right: an unpinned restatement of the crate's simdeez_f build)"
     # for honesty: the same search freed of the reference's data model (flat arrays, epoch visited array, SIMD-order
     # sums, prefetch: oracle/flat_baseline.hpp) -- what the host cores can do, NOT the reference's cost structure
     flat = orc.flat_baseline()

@@ -145,7 +145,10 @@ struct PinnedBuf {
     void* p = nullptr;
     void* dev = nullptr;
     uint64_t cap = 0;
+    uint64_t need = 0;       // what the last call asked for
+    unsigned small_calls = 0;  // consecutive calls that did not need the size this buffer has grown to (see trim)
     hipError_t ensure(uint64_t bytes) {
+        need = bytes;
         if (bytes <= cap) return hipSuccess;
         free();
         const uint64_t want = std::max<uint64_t>(bytes, 1u << 16);
@@ -156,8 +159,14 @@ struct PinnedBuf {
         cap = want;
         return hipSuccess;
     }
-    // staging memory of an unusually large batch is given back when its workspace returns to the pool
-    void trim(uint64_t keep_bytes) { if (cap > keep_bytes) free(); }
+    // Staging memory of an unusually large batch is given back -- but not by the caller whose batches ARE that large: only after
+    // eight calls in a row that did not need it (freeing and pinning hundreds of MB again on every call costs tens of ms and a
+    // device synchronisation each time).
+    void trim(uint64_t keep_bytes) {
+        if (cap <= keep_bytes) return;
+        if (need > keep_bytes) { small_calls = 0; return; }
+        if (++small_calls >= 8u) { free(); small_calls = 0; }
+    }
     void free() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
@@ -235,6 +244,7 @@ DeviceIndex::Workspace* DeviceIndex::acquire(std::string& err) {
 }
 void DeviceIndex::release_ws(Workspace* w) {
     // pinned staging memory only ever grew: a single 100 000 x 784 batch left hundreds of MB pinned on every pooled workspace
+    // (PinnedBuf::trim: given back after eight calls that did not need it)
     w->pin_in.trim(64ull << 20);
     w->pin_out.trim(64ull << 20);
     std::lock_guard<std::mutex> g(pool_mu_);
@@ -862,6 +872,17 @@ struct HostCall {
     // Busy waiting for as long as the search of a usual batch lasts (4 ms by the clock -- a count of `pause` instructions is 1.2 ms
     // on one CPU and 3 ms on another, and a helper that dozes off just before the answers arrive makes its section end 50-150 us
     // late: measured, the call went from 1.25 to 1.40 ms whenever the search took a little longer), then polite polling.
+    // The busy wait is for the lone caller that issues call after call: with several host-buffer calls in flight (concurrent
+    // callers on one or more handles) the helpers of all of them would spin on cores the callers' own gathers need -- they then
+    // spin for 200 us only and nap.
+    static std::atomic<int>& calls_in_flight() {
+        static std::atomic<int> n{0};
+        return n;
+    }
+    struct InFlight {
+        InFlight() { calls_in_flight().fetch_add(1, std::memory_order_relaxed); }
+        ~InFlight() { calls_in_flight().fetch_sub(1, std::memory_order_relaxed); }
+    };
     struct Spin {
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         unsigned n = 0;
@@ -869,8 +890,15 @@ struct HostCall {
     };
     static void relax(Spin& w) {
         if (!w.napping) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
-            if ((++w.n & 255u) == 0u && std::chrono::steady_clock::now() - w.t0 > std::chrono::milliseconds(4)) w.napping = true;
+#else
+            std::this_thread::yield();
+#endif
+            if ((++w.n & 255u) == 0u) {
+                const auto budget = calls_in_flight().load(std::memory_order_relaxed) <= 1 ? std::chrono::microseconds(4000) : std::chrono::microseconds(200);
+                if (std::chrono::steady_clock::now() - w.t0 > budget) w.napping = true;
+            }
         } else {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
@@ -883,6 +911,7 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
                                     CallInfo* info, std::string& err) {
     if (!ready_) { err = "index is not resident on a device: call hnswgpu_upload first"; return ERR_DEVICE; }
     if (nq == 0) { if (info) *info = CallInfo{}; return OK; }
+    HostCall::InFlight in_flight;  // (how long this call's helpers may spin depends on how many calls there are: HostCall::relax)
     if ((!queries && !rows) || !sink.rows) { err = "null buffer"; return ERR_ARG; }
     if (d != v_.d) { err = "query dimension differs from the index dimension"; return ERR_ARG; }
     if (k == 0) { err = "knbn must be > 0"; return ERR_ARG; }

@@ -75,8 +75,9 @@ public:
         if (err) std::rethrow_exception(err);
     }
 
-    // An asynchronous one-off job (a ticket of the C ABI): runs on a pool thread as soon as one is free -- one is created when
-    // all are busy, so a job never queues behind a long section.  wait() blocks until it has run; a job that throws is the
+    // An asynchronous one-off job (a ticket of the C ABI): runs on a pool thread of its own -- one is created when the idle ones are
+    // spoken for -- so a job queues neither behind a long section nor behind another job; when no thread can be had at all it runs
+    // on the caller.  wait() blocks until it has run; a job that throws is the
     // caller's bug (jobs catch their own errors).
     class Job {
     public:
@@ -97,16 +98,21 @@ public:
         bool queued = false;
         {
             std::lock_guard<std::mutex> g(mu_);
-            if (idle_ > 0 || n_threads_ < HARD_CAP) {
-                queue_.push_front(Item{nullptr, j});  // ahead of invitations: a job has no caller working on it
+            // A thread per waiting job: the idle (or just created) threads may all be spoken for by jobs queued a moment ago --
+            // two tickets issued back to back must not run one after the other on the one idle thread.
+            bool have_thread = idle_ + spawning_ > queued_jobs_;
+            if (!have_thread && n_threads_ < HARD_CAP) have_thread = spawn_locked();
+            if (have_thread || idle_ + spawning_ > 0) {  // (no thread of its own but some thread will come by: it waits its turn)
+                // ahead of the invitations (a job has no caller working on it), behind the jobs already waiting (first in, first out)
+                queue_.insert(queue_.begin() + (std::ptrdiff_t)queued_jobs_, Item{nullptr, j});
+                ++queued_jobs_;
                 pending_.fetch_add(1, std::memory_order_relaxed);
-                if (idle_ == 0) spawn_locked();
                 queued = true;
             }
         }
         if (queued) {
             cv_.notify_one();
-        } else {  // no thread to be had: run it here rather than never
+        } else {  // no thread to be had and none idle: run it here rather than never
             run_job(*j);
         }
         return j;
@@ -196,6 +202,7 @@ private:
             --idle_;
             Item it = std::move(queue_.front());
             queue_.pop_front();
+            if (it.job) --queued_jobs_;  // (jobs sit in front of the invitations)
             pending_.fetch_sub(1, std::memory_order_relaxed);
             g.unlock();
             if (it.job) {
@@ -214,6 +221,7 @@ private:
     std::condition_variable cv_;
     std::deque<Item> queue_;
     unsigned n_threads_ = 0, idle_ = 0, spawning_ = 0;
+    unsigned queued_jobs_ = 0;          // jobs at the front of queue_ (in arrival order), not yet taken by a thread
     std::atomic<unsigned> pending_{0};  // items in queue_ (read without the lock by lingering threads)
     std::atomic<unsigned> lingering_{0};  // idle threads that are awake, polling pending_
     int linger_us_ = 200;

@@ -267,10 +267,15 @@ int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
 /* The arithmetic of Distance<f32>::eval during SEARCH (construction always sums like the scalar build).
  *   HNSWGPU_ARITH_SCALAR (default): the crate's default build -- every sum left to right over the vector index
  *                                   (anndists 0.1 without features, Cargo.toml:104-106); what the parity tests pin.
- *   HNSWGPU_ARITH_SIMD8:            the summation order of its `simdeez_f` / `stdsimd` builds (Cargo.toml:107-111; the
- *                                   builds behind every number the reference publishes, README.md:46-56): 8 vertical f32
- *                                   accumulators over the full blocks of 8 elements, their horizontal sum, then the d % 8
- *                                   tail; DistCosine with three such f32 sums.  DistL2 / DistCosine / DistDot / DistL1 only
+ *   HNSWGPU_ARITH_SIMD8:            an APPROXIMATION of the summation order of its `simdeez_f` / `stdsimd` builds
+ *                                   (Cargo.toml:107-111; the builds behind every number the reference publishes,
+ *                                   README.md:46-56): 8 vertical f32 accumulators over the full blocks of 8 elements, their
+ *                                   horizontal sum LEFT TO RIGHT, then the d % 8 tail; DistCosine with three such f32 sums.
+ *                                   The crate's sources are not available here: its vector width follows the ISA chosen at
+ *                                   run time, its horizontal add may fold halves pairwise, and DistCosine may have no SIMD
+ *                                   kernel at all -- so this mode is checked against the oracle's dist_simd8 only, and is
+ *                                   NOT claimed to reproduce a simdeez_f build bit for bit until oracle/ref_pin has been run
+ *                                   with `--features simdeez_f` (.github/workflows/pin.yml does).  DistL2 / DistCosine / DistDot / DistL1 only
  *                                   (other distances keep the scalar order).  Last-bit differences to the scalar build, so
  *                                   near-tie ids may differ from it; the checker for this mode is the oracle's dist_simd8.
  * Opt-in, never the default.  Takes effect for the following search calls on every replica of the index.            */

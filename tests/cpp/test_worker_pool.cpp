@@ -92,6 +92,38 @@ int main() {
         stop.store(true);
         busy.join();
     }
+    // 6b. two jobs issued back to back do not share one thread (with ONE idle thread both went to the front of the
+    // queue and ran one after the other, newest first): each waits for the other to have started -- that only ends if they overlap
+    for (int round = 0; round < 50; ++round) {
+        std::atomic<int> started{0};
+        std::atomic<bool> gave_up{false};
+        auto body = [&]() {
+            started.fetch_add(1);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (started.load() < 2) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { gave_up.store(true); break; }
+                std::this_thread::yield();
+            }
+        };
+        auto j1 = pool.submit(body);
+        auto j2 = pool.submit(body);
+        j1->wait();
+        j2->wait();
+        if (gave_up.load()) { std::printf("two jobs issued back to back ran one after the other (round %d)\n", round); return 1; }
+        if (round % 5 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));  // (threads asleep again)
+    }
+    // 6c. jobs start in the order they were submitted (first in, first out among themselves)
+    {
+        std::mutex m;
+        std::vector<int> order;
+        std::vector<std::shared_ptr<WorkerPool::Job>> js;
+        std::atomic<bool> stop{false};
+        // keep every thread the pool may create for sections busy, and the idle ones asleep, so that the jobs really queue
+        for (int i = 0; i < 16; ++i) js.push_back(pool.submit([&, i]() { std::lock_guard<std::mutex> g(m); order.push_back(i); }));
+        for (auto& j : js) j->wait();
+        (void)stop;
+        if (order.size() != 16u) { std::printf("fifo: %zu of 16 jobs ran\n", order.size()); return 1; }
+    }
     // 7. a pool that has grown large (a build on every core) and small sections after it, at gaps shorter and longer than the
     // helpers' lingering time: the section wakes only the sleepers the lingering threads leave work for -- every task still runs
     // exactly once, helpers still take part (not always: a section never waits for one), and a section of 8 short tasks is not
