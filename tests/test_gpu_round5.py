@@ -1,5 +1,6 @@
-"""Round-5 GPU tests: RCCL entered on the 1-GPU box (a one-rank process group running the N > 1 exchange), the native
-peer gather of the sharded C-ABI call, the lane algorithms of the search kernel run on the device from scripts."""
+"""Round-5 GPU tests: RCCL entered on the 1-GPU box (a one-rank process group running the N > 1 exchange).  The round's other GPU
+tests live where they belong: the native peer gather of the sharded C-ABI call in tests/test_gpu_round4.py (config 4 at its own
+size), the lane algorithms of the search kernels run on the device from scripts in tests/test_gpu_lane_lab.py."""
 import json
 import os
 import subprocess
