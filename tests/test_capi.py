@@ -151,3 +151,24 @@ def test_host_distance_callback_is_refused_with_a_reason(native):
     cb = C.CFUNCTYPE(C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_ulonglong)(lambda a, b, n: 0.0)
     assert not lib.init_hnsw_ptrdist_f32(16, 200, C.cast(cb, C.c_void_p))
     assert "callback" in native._native.last_error()
+
+
+def test_round5_entry_points_check_their_arguments_without_a_device(native):
+    """hnswgpu_gather_sharded_answers / hnswgpu_lane_lab: argument errors are reported as status codes (no device needed to find
+    them, nothing aborts), and without a HIP device the calls fail with the device error -- there is no CPU fallback."""
+    lib = native.lib()
+    one = np.zeros(4, np.uint32)
+    # null buffers / bad shapes
+    assert lib.hnswgpu_gather_sharded_answers(None, 1, None, 10, None, None, None, None, None, 0, None, None, None, None, None, None) != 0
+    devs = (C.c_int * 1)(0)
+    cnt = (C.c_uint64 * 1)(4)
+    nullp = (C.c_void_p * 1)(None)
+    assert lib.hnswgpu_gather_sharded_answers(devs, 1, cnt, 10, nullp, nullp, None, None, nullp, 0, None, None, None, None, None, None) != 0
+    assert "null" in native._native.last_error() or "bad" in native._native.last_error()
+    assert lib.hnswgpu_lane_lab(0, 9, 0, 0, 0, one.ctypes.data, 1, None, 0, one.ctypes.data, 4) != 0          # no such mode
+    assert lib.hnswgpu_lane_lab(0, 1, 3, 0, 0, one.ctypes.data, 1, None, 0, one.ctypes.data, 4) != 0          # 3 slots per lane
+    assert lib.hnswgpu_lane_lab(0, 2, 1, 65, 0, one.ctypes.data, 1, None, 0, one.ctypes.data, 4) != 0         # ef beyond 64 entries
+    assert lib.hnswgpu_lane_lab(0, 3, 11, 20, 11, one.ctypes.data, 1, None, 0, one.ctypes.data, 4) != 0       # restbits != idbits - (tbits - 3)
+    assert lib.hnswgpu_lane_lab(0, 0, 8, 0, 0, None, 1, None, 0, one.ctypes.data, 4) != 0                     # null script
+    if lib.hnswgpu_device_count() == 0:
+        assert lib.hnswgpu_lane_lab(0, 0, 8, 0, 0, one.ctypes.data, 1, None, 0, one.ctypes.data, 4) != 0      # no device: an error, not a CPU run
