@@ -768,6 +768,7 @@ def main():
     # serves concurrent calls from a workspace pool).  One launch ends with its longest search while the machine
     # drains; a second batch in flight fills that tail.  Not `value`: one caller, one batch at a time.
     two_callers_qps = None
+    tickets_qps = None
     if world == 1 and not args.no_concurrent:
         import threading
         lanes = []
@@ -809,6 +810,35 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"two-caller measurement skipped: {e}")
             two_callers_qps = None
+        # the same overlap from ONE host thread through the library's asynchronous calls (hnswgpu_search_batch_device_begin /
+        # hnswgpu_search_batch_end: a ticket per batch, two in flight) -- what a Rust host would do instead of a second thread
+        try:
+            def run_tickets(nsteps):
+                fence()
+                t0 = time.perf_counter()
+                pending = []
+                for i in range(nsteps):
+                    ln = lanes[i % 2]
+                    if len(pending) == 2:
+                        if lib.hnswgpu_search_batch_end(pending.pop(0)) != 0:
+                            raise RuntimeError(H._native.last_error())
+                    tk = C.c_void_p()
+                    rc = lib.hnswgpu_search_batch_device_begin(index.handle, Qds[i % NB].data_ptr(), nq_local, d, k, ef, ln["ids"].data_ptr(),
+                                                               ln["dists"].data_ptr(), ln["layer"].data_ptr(), ln["rank"].data_ptr(),
+                                                               ln["counts"].data_ptr(), ln["stats"].data_ptr(), ln["stream"].cuda_stream, C.byref(tk))
+                    if rc != 0:
+                        raise RuntimeError(H._native.last_error())
+                    pending.append(tk)
+                for tk in pending:
+                    if lib.hnswgpu_search_batch_end(tk) != 0:
+                        raise RuntimeError(H._native.last_error())
+                fence()
+                return time.perf_counter() - t0
+            run_tickets(2 * max(1, args.warmup))
+            tickets_qps = nq_total * args.steps / run_tickets(args.steps)
+        except Exception as e:  # noqa: BLE001
+            log(f"two-ticket measurement skipped: {e}")
+            tickets_qps = None
     boundary = None
     orc = None  # the oracle: checker and CPU baseline (rank 0, N = 1 only), never on the product path
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -961,6 +991,7 @@ def main():
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},
             "simd_order_queries_per_s": None if simd_qps is None else round(simd_qps, 1),
             "two_caller_threads_queries_per_s": None if two_callers_qps is None else round(two_callers_qps, 1),
+            "one_caller_two_tickets_queries_per_s": None if tickets_qps is None else round(tickets_qps, 1),
             # `value` is the device-resident call (queries already in HBM when the timed region starts, answers left in HBM: the
             # measurement contract of this build).  The reference's API is host buffers (src/libext.rs:205-254, BASELINE.md section 2:
             # "one batched call including host->device query copy and device->host result copy"): that call, same box, same batch:
