@@ -695,6 +695,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             lds += (size_t)a.merge_entries * sizeof(hent_t);
         }
         int per_cu = 0;
+        int strict_cap = STRICT_WG_PER_CU;
+        if (const char* e = std::getenv("HNSWGPU_STRICT_WG_PER_CU")) strict_cap = std::max(1, std::atoi(e));  // tuning hook
         if (strict_kernel) {
             // top levels of the (lazy) literal candidate heap, for the few pops that need it: 512 entries when that costs no
             // resident wave (the strict kernel sits at 4 waves per SIMD by its registers, which leaves ~10 KB of LDS per
@@ -706,7 +708,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
                 int occ256 = 0, occ512 = 0;
                 HIP_TRY(ks.occupancy(slots, table, true, lds + 256 * sizeof(hent_t), &occ256));
                 HIP_TRY(ks.occupancy(slots, table, true, lds + 512 * sizeof(hent_t), &occ512));
-                if (std::min(occ512, STRICT_WG_PER_CU) >= std::min(occ256, STRICT_WG_PER_CU)) a.cand_lds = 512;
+                if (std::min(occ512, strict_cap) >= std::min(occ256, strict_cap)) a.cand_lds = 512;
             }
             lds += (size_t)a.cand_lds * sizeof(hent_t);
         }
@@ -716,7 +718,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         // per SIMD slows every expansion of it: with the descent out of the kernel the strict kernel needs 89 VGPRs and would
         // fit 20 workgroups per CU; measured (config 2, one box) 7.63 M queries/s at 20, 8.49 M at 16.  The lean kernel gains
         // from its 20 (9.7 M) and keeps them.
-        if (strict_kernel) per_cu = std::min(per_cu, STRICT_WG_PER_CU);
+        if (strict_kernel) per_cu = std::min(per_cu, strict_cap);
         if (const char* e = std::getenv("HNSWGPU_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // tuning hook
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
         if (std::getenv("HNSWGPU_TRACE_LAUNCH"))  // diagnostics: what bounds the resident workgroups of this launch
