@@ -116,6 +116,8 @@ def test_memory_heap_equals_std_binaryheap(native, oracle, lds_cap, pop3, ties):
     for n_ops in (5, 40, 300, 1500):
         ops, lanes, vals, tags, is_pop = heap_case(rnd, n_ops, ties, batches=False)
         check_heap(run_lab(native, 0, lds_cap, pop3, 0, ops), oracle, vals, tags, is_pop)
+        # the same script with the pushes a log replay uses (no parent probe in front of the ancestor chain)
+        check_heap(run_lab(native, 0, lds_cap, pop3, 1, ops), oracle, vals, tags, is_pop)
 
 
 @pytest.mark.parametrize("ties", [False, True])
