@@ -7,9 +7,13 @@ over one batch of synthetic queries: greedy layer descent + layer-0 ef-expansion
 of the batch, inputs already resident in HBM.  Rank 0 prints ONE JSON line.
 
 Workload at N=1 (BASELINE.json configs[1]): SIFT1M-shape synthetic, 1M x 128 f32, DistL2, M=16,
-ef_construction=200, ef=64, k=10, 10 000 queries.  For N>1 (configs[3]) the graph is replicated
-on every GPU and 12 500 queries per GPU are searched (100 000 over 8 GPUs), then all-gathered
-over RCCL; per-GPU work is fixed => "weak" scaling.
+ef_construction=200, ef=64, k=10, 10 000 queries.  For N>1 the workload is BASELINE.json configs[3]
+as it is stated: ONE batch of 100 000 queries (what `parallel_search` answers in one call,
+src/hnsw.rs:1612-1635) split into N contiguous blocks of 100 000 / N, the graph replicated on every
+GPU, the answers all-gathered over RCCL: the total work is fixed => "strong" scaling, and every N>1
+line carries `one_gpu_same_batch_queries_per_s` -- the same 100 000 queries in one call on rank 0's
+GPU, same invocation -- so that the 1 -> N ratio is read off one line.  `--weak` keeps the fixed
+12 500 queries per GPU of the earlier rounds (per-GPU work fixed => "weak").
 
 What is untimed setup: synthetic data, graph construction on the host cores (product builder,
 cached as an hnswio dump under --cache-dir), dump reload, HBM upload, exact ground truth (torch
@@ -31,17 +35,17 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 CONFIGS = {
-    # name: n, d, dist, M, ef_c, k, ef, nq (N=1), nq per GPU (N>1)
-    "sift1m": dict(n=1_000_000, d=128, dist="DistL2", M=16, efc=200, k=10, ef=64, nq=10_000, nq_multi=12_500,
+    # name: n, d, dist, M, ef_c, k, ef, nq (N=1), nq per GPU (N>1, --weak), queries of the ONE batch N>1 GPUs share (strong scaling)
+    "sift1m": dict(n=1_000_000, d=128, dist="DistL2", M=16, efc=200, k=10, ef=64, nq=10_000, nq_multi=12_500, nq_total_multi=100_000,
                    label="SIFT1M-shape synthetic 1Mx128 f32 L2 M=16 ef=64"),
-    "glove25": dict(n=1_200_000, d=25, dist="DistCosine", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000,
+    "glove25": dict(n=1_200_000, d=25, dist="DistCosine", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000, nq_total_multi=80_000,
                     label="GloVe-25-shape synthetic 1.2Mx25 f32 cosine M=24 ef=128"),
     # the reference's own choice for this data set: DistDot on L2-normalised vectors (examples/ann-glove25-angular.rs:81-82, :107-108)
-    "glove25_dot": dict(n=1_200_000, d=25, dist="DistDot", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000,
+    "glove25_dot": dict(n=1_200_000, d=25, dist="DistDot", M=24, efc=400, k=10, ef=128, nq=10_000, nq_multi=10_000, nq_total_multi=80_000,
                         label="GloVe-25-shape synthetic 1.2Mx25 f32, L2-normalised, DistDot M=24 ef=128"),
-    "mnist784": dict(n=60_000, d=784, dist="DistL2", M=32, efc=400, k=10, ef=200, nq=10_000, nq_multi=10_000,
+    "mnist784": dict(n=60_000, d=784, dist="DistL2", M=32, efc=400, k=10, ef=200, nq=10_000, nq_multi=10_000, nq_total_multi=80_000,
                      label="MNIST-784-shape synthetic 60kx784 f32 L2 M=32 ef=200"),
-    "random10k": dict(n=10_000, d=25, dist="DistL2", M=15, efc=200, k=10, ef=24, nq=1_000, nq_multi=1_000,
+    "random10k": dict(n=10_000, d=25, dist="DistL2", M=15, efc=200, k=10, ef=24, nq=1_000, nq_multi=1_000, nq_total_multi=8_000,
                       label="random.rs shape 10kx25 f32 L2 M=15 ef=24"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
@@ -49,6 +53,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spe
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def plan_queries(cfg, world, nq_override=0, weak=False):
+    """Who searches what.  N = 1: the config's batch.  N > 1: BASELINE.json configs[3] as stated -- ONE batch (`nq_total_multi`
+    queries: 100 000 for the SIFT1M shape) cut into `world` contiguous blocks of equal size, total work fixed: "strong" scaling
+    (a total that `world` does not divide loses its last few queries, and says so).  --weak: `nq_multi` queries per GPU whatever
+    N is (per-GPU work fixed).  --nq overrides the per-GPU count and makes the run a weak one."""
+    if world == 1:
+        nq_local = nq_override or cfg["nq"]
+        return {"nq_local": nq_local, "nq_total": nq_local, "scaling": "weak", "mode": "one GPU, one batch", "dropped": 0}
+    if nq_override or weak:
+        nq_local = nq_override or cfg["nq_multi"]
+        return {"nq_local": nq_local, "nq_total": nq_local * world, "scaling": "weak",
+                "mode": f"{nq_local} queries per GPU whatever N is (--weak / --nq)", "dropped": 0}
+    total = cfg["nq_total_multi"]
+    nq_local = total // world
+    return {"nq_local": nq_local, "nq_total": nq_local * world, "scaling": "strong",
+            "mode": f"one batch of {total} queries in {world} contiguous blocks of {nq_local} (BASELINE.json configs[3])",
+            "dropped": total - nq_local * world}
 
 
 def synth(n, d, seed, kind):
@@ -273,6 +296,8 @@ def spawn_ranks(args):
     import subprocess
     import torch
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.plan_only:
+        ndev = args.gpus  # (the plan needs no device: the ranks meet over gloo)
     if ndev == 0:
         print("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)", file=sys.stderr)
         return 2
@@ -532,6 +557,10 @@ def main():
     ap.add_argument("--dump-answers", default="", help="write the answers of batch 0 (all ranks' shards gathered, input order) to this .npz")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (gloo only to exercise the multi-rank path on a 1-GPU box)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: a fixed number of queries per GPU (12 500 for the SIFT1M shape) "
+                    "instead of ONE batch of 100 000 split N ways")
+    ap.add_argument("--plan-only", action="store_true", help="N > 1: the ranks only rendezvous (gloo, no GPU needed), agree on who "
+                    "searches which block of the batch, and rank 0 prints that plan as JSON (tests/test_sharding.py)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (1-GPU box test of the N>1 path)")
     ap.add_argument("--exchange", action="store_true",
                     help="N = 1 only: run the N > 1 exchange anyway -- a ONE-rank process group of --backend (nccl = RCCL) and the same "
@@ -552,6 +581,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): pass the same number to both")
+    if args.plan_only:
+        # no device: every rank works out the plan, the ranks gather the block each of them would search, rank 0 prints it
+        import datetime
+        import torch.distributed as dist
+        from hnsw_rs_amd.sharded import shard_bounds
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+        plan = plan_queries(CONFIGS[args.config], world, args.nq, args.weak)
+        lo, hi = shard_bounds(plan["nq_total"], world, rank)
+        mine = torch.tensor([lo, hi], dtype=torch.int64)
+        blocks = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(blocks, mine)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "config": {"queries_total": plan["nq_total"], "queries_per_gpu": plan["nq_local"]},
+                              "scaling": plan["scaling"], "plan": plan["mode"], "queries_dropped": plan["dropped"],
+                              "blocks": [[int(b[0]), int(b[1])] for b in blocks]}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
     if args.share_device:
@@ -602,7 +650,8 @@ def main():
         cfg["n"] = args.n
     if args.ef:
         cfg["ef"] = args.ef
-    nq_local = args.nq or (cfg["nq"] if world == 1 else cfg["nq_multi"])
+    plan = plan_queries(cfg, world, args.nq, args.weak)
+    nq_local = plan["nq_local"]
     n, d, k, ef = cfg["n"], cfg["d"], cfg["k"], cfg["ef"]
     H.build_native()
     lib = H.lib()
@@ -740,6 +789,36 @@ def main():
         gather_ms = float(np.median(gather_marks)) * 1e3
         kernel_ms[:] = kernel_ms[:len(timed_kernel_ms)]
         main_ms[:] = main_ms[:len(timed_main_ms)]
+
+    # N > 1 (one batch shared by the GPUs): the same batch -- all nq_total queries -- in ONE call on rank 0's GPU, untimed by the
+    # contract's clock: what a single GPU makes of BASELINE.json configs[3], on this box, this graph, this invocation
+    one_gpu_qps = None
+    if world > 1 and plan["scaling"] == "strong":
+        fence()
+        if rank == 0:
+            Qw = torch.from_numpy(np.ascontiguousarray(Q_all[:nq_total])).to(dev)
+            w_ids = torch.zeros((nq_total, k), dtype=torch.int64, device=dev)
+            w_d = torch.zeros((nq_total, k), dtype=torch.float32, device=dev)
+            w_cnt = torch.zeros((nq_total,), dtype=torch.int32, device=dev)
+            w_layer = torch.zeros((nq_total, k), dtype=torch.uint8, device=dev)
+            w_rank = torch.zeros((nq_total, k), dtype=torch.int32, device=dev)
+            w_stats = torch.zeros((nq_total, 8), dtype=torch.int32, device=dev)
+
+            def whole():
+                rc = lib.hnswgpu_search_batch_device(index.handle, Qw.data_ptr(), nq_total, d, k, ef, w_ids.data_ptr(), w_d.data_ptr(),
+                                                     w_layer.data_ptr(), w_rank.data_ptr(), w_cnt.data_ptr(), w_stats.data_ptr(), stream.cuda_stream)
+                if rc != 0:
+                    raise RuntimeError(H._native.last_error())
+            whole()
+            torch.cuda.synchronize(dev)
+            reps = max(2, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                whole()
+            torch.cuda.synchronize(dev)
+            one_gpu_qps = nq_total * reps / (time.perf_counter() - t0)
+            del Qw, w_ids, w_d, w_cnt, w_layer, w_rank, w_stats
+        fence()
 
     # untimed accounting: one more step per batch for its work counters (the algorithmic bytes of that batch)
     batch_stats = []
@@ -975,17 +1054,21 @@ def main():
         out = {
             "metric": "queries/sec (+ recall@10), batched HNSW search",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": plan["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": f"synthetic ({args.data}, seeds 0x5EED0001/0x5EED0002), graph built by the product builder ({'host cores' if args.host_build else 'GPU-assisted construction'})",
             "config": {"workload": cfg["label"], "n": n, "d": d, "distance": cfg["dist"], "M": cfg["M"],
                        "ef_construction": cfg["efc"], "ef": ef, "k": k, "queries_per_gpu": nq_local,
-                       "queries_total": nq_total, "graph": "replicated per GPU",
+                       "queries_total": nq_total, "query_plan": plan["mode"], "graph": "replicated per GPU",
                        "exchange": ("one all_gather_into_tensor per step of the packed answers (ids | distances | counts, %d bytes per rank) over %s, "
                                     "issued asynchronously: it overlaps the search of the next step (two answer buffers alternate); the timed "
                                     "region ends with every exchange complete" % (xch.shard_bytes, "RCCL" if backend_used == "nccl" else "gloo")) if pg else "none",
                        "parallelism": f"{world} x (replica + {nq_local} queries)"},
             "rccl": rccl,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+            # N > 1, strong scaling: the WHOLE batch (queries_total) in one call on rank 0's GPU, same invocation, same graph:
+            # value / this = the speed-up of N GPUs over one on BASELINE.json configs[3]
+            "one_gpu_same_batch_queries_per_s": None if one_gpu_qps is None else round(one_gpu_qps, 1),
+            "speedup_over_one_gpu_same_batch": None if one_gpu_qps is None else round(qps / one_gpu_qps, 3),
             "recall_at_10": None if args.no_recall else {"by_id": round(float(recall_id), 4), "by_distance_threshold": round(float(recall_dist), 4)},
             "strict_ties": {"on": True, "note": "queries whose answer depends on the internal order of the reference's BinaryHeaps (equal f32 distances at a decisive place) carry on with a literal emulation of the heap in question (DESIGN.md section 6)",
                             "fast_mode_queries_per_s": None if fast_qps is None else round(fast_qps, 1)},

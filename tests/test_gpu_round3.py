@@ -41,6 +41,13 @@ def test_bench_gpus_2_as_a_plain_command_gathers_the_one_gpu_answers(tmp_path):
     assert np.array_equal(one["counts"], two["counts"])
     assert np.array_equal(one["ids"], two["ids"])
     assert np.array_equal(one["dists"].view(np.uint32), two["dists"].view(np.uint32))
+    # without --nq the N > 1 command is BASELINE config 4's plan: ONE batch shared by the ranks (8 000 queries for this small
+    # shape), "strong", with the same batch on one GPU measured in the same invocation
+    r3, j3 = _bench(["--gpus", "2", "--share-device", "--backend", "nccl", "--config", "random10k", "--steps", "2", "--warmup", "1",
+                     "--no-cpu-baseline", "--no-recall", "--no-concurrent", "--cache-dir", cache])
+    assert r3.returncode == 0 and j3 is not None, r3.stdout[-2000:] + r3.stderr[-4000:]
+    assert j3["scaling"] == "strong" and j3["config"]["queries_total"] == 8000 and j3["config"]["queries_per_gpu"] == 4000
+    assert j3["one_gpu_same_batch_queries_per_s"] > 0 and j3["speedup_over_one_gpu_same_batch"] > 0
 
 
 # ------------------------------------------------------------------------------------------------- full size

@@ -77,6 +77,47 @@ def test_bench_gpus_n_is_a_plain_command():
     assert "HIP device" in r.stderr and not r.stdout.strip()
 
 
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_plan_n_gpus_share_one_batch_of_100000():
+    """BASELINE.json configs[3] as stated (src/hnsw.rs:1612-1635 answers ONE batch): N > 1 GPUs share the 100 000 queries, total work
+    fixed = strong scaling; --weak / --nq keep a fixed count per GPU; N = 1 is config 2's 10 000."""
+    b = _load_bench()
+    cfg = b.CONFIGS["sift1m"]
+    assert b.plan_queries(cfg, 1) == {"nq_local": 10000, "nq_total": 10000, "scaling": "weak", "mode": "one GPU, one batch", "dropped": 0}
+    for n in (2, 4, 8):
+        p = b.plan_queries(cfg, n)
+        assert p["nq_total"] == 100000 and p["nq_local"] == 100000 // n and p["scaling"] == "strong" and p["dropped"] == 0
+    p = b.plan_queries(cfg, 8, weak=True)
+    assert p["nq_local"] == 12500 and p["nq_total"] == 100000 and p["scaling"] == "weak"
+    p = b.plan_queries(cfg, 4, weak=True)
+    assert p["nq_local"] == 12500 and p["nq_total"] == 50000 and p["scaling"] == "weak"
+    p = b.plan_queries(cfg, 2, nq_override=500)
+    assert p["nq_local"] == 500 and p["nq_total"] == 1000 and p["scaling"] == "weak"
+    p = b.plan_queries(cfg, 3)  # a count 100 000 is not a multiple of: equal blocks, the remainder dropped and reported
+    assert p["nq_local"] == 33333 and p["nq_total"] == 99999 and p["dropped"] == 1
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_bench_gpus_n_plan_through_the_launcher(n):
+    """`python bench.py --gpus N --plan-only`: the command launches its N ranks (gloo, no device), every rank works the plan out and
+    the blocks they would search are gathered: 100 000 queries in all, N contiguous blocks in input order, "strong"."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--plan-only", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == n and j["scaling"] == "strong"
+    assert j["config"]["queries_total"] == 100000 and j["config"]["queries_per_gpu"] == 100000 // n
+    assert j["blocks"] == [[i * (100000 // n), (i + 1) * (100000 // n)] for i in range(n)]
+
+
 WORKER_OVERLAP = textwrap.dedent("""
     import os, sys, time
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
