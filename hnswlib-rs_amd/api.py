@@ -404,3 +404,8 @@ def eval_distances(dist, a, b):
     out = np.zeros(a.shape[0], np.float32)
     _check(N.lib().hnswgpu_eval_distances(N.DIST[dist], _p(a), _p(b), a.shape[0], a.shape[1], _p(out)))
     return out
+
+
+def reload_env():
+    """The HNSWGPU_* tuning / test hooks are read from the environment once per process; call this after changing them."""
+    _check(N.lib().hnswgpu_reload_env())

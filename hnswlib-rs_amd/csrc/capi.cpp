@@ -740,6 +740,10 @@ int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on) {
     for (auto& kv : idx->replicas) kv.second->set_strict_ties(idx->strict_ties != 0);
     return HNSWGPU_OK;
 }
+int hnswgpu_reload_env(void) {
+    hnswgpu::reload_knobs();
+    return HNSWGPU_OK;
+}
 int hnswgpu_last_tie_count(const hnswgpu_index* cidx, uint32_t* ties) {
     hnswgpu_index* idx = const_cast<hnswgpu_index*>(cidx);
     if (!idx || !ties) return fail(HNSWGPU_ERR_ARG, "null argument");
@@ -1050,7 +1054,7 @@ const Vec_api_Neighbourhood* parallel_search_neighbours_f32(const HnswApif32* ap
         [](void* ctx, uint64_t nq, uint64_t k) -> bool {
             FfiAnswer& f = *static_cast<FfiAnswer*>(ctx);
             const size_t bytes = sizeof(SlabHeader) + sizeof(Vec_api_Neighbourhood) + nq * sizeof(Neighbourhood_api) + nq * k * sizeof(Neighbour_api);
-            const bool unpack_only = std::getenv("HNSWGPU_FFI_UNPACK") != nullptr;
+            const bool unpack_only = hnswgpu::knobs().ffi_unpack;
             SlabHeader* h = slab_cache().take(bytes, !unpack_only);
             if (!h) return false;
             unsigned char* slab = reinterpret_cast<unsigned char*>(h);

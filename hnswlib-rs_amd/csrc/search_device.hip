@@ -38,6 +38,40 @@
 namespace hnswgpu {
 
 namespace {
+Knobs read_knobs() {
+    Knobs k;
+    auto num = [](const char* name, int unset) { const char* e = std::getenv(name); return e ? std::atoi(e) : unset; };
+    auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
+    k.hash_bits = num("HNSWGPU_HASH_BITS", -1);
+    k.no_sched = flag("HNSWGPU_NO_SCHED");
+    k.no_inkernel = flag("HNSWGPU_NO_INKERNEL");
+    k.strict_wg_per_cu = num("HNSWGPU_STRICT_WG_PER_CU", -1);
+    k.cand_lds = num("HNSWGPU_CAND_LDS", -1);
+    k.waves_per_cu = num("HNSWGPU_WAVES_PER_CU", -1);
+    k.exact_first = num("HNSWGPU_EXACT_FIRST", -1);
+    k.trace_launch = flag("HNSWGPU_TRACE_LAUNCH");
+    k.trace_host = flag("HNSWGPU_TRACE_HOST");
+    k.host_threads = num("HNSWGPU_HOST_THREADS", -1);
+    k.host_chunks = num("HNSWGPU_HOST_CHUNKS", -1);
+    k.ffi_unpack = flag("HNSWGPU_FFI_UNPACK");
+    return k;
+}
+std::atomic<const Knobs*> g_knobs{nullptr};
+}  // namespace
+const Knobs& knobs() {
+    const Knobs* k = g_knobs.load(std::memory_order_acquire);
+    if (k == nullptr) {
+        const Knobs* fresh = new Knobs(read_knobs());
+        if (g_knobs.compare_exchange_strong(k, fresh, std::memory_order_acq_rel)) k = fresh;
+        else delete fresh;
+    }
+    return *k;
+}
+void reload_knobs() {  // (the previous set stays allocated: a call in flight may still be reading it; a few dozen bytes per reload)
+    g_knobs.store(new Knobs(read_knobs()), std::memory_order_release);
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -163,8 +197,10 @@ struct PinnedBuf {
     // eight calls in a row that did not need it (freeing and pinning hundreds of MB again on every call costs tens of ms and a
     // device synchronisation each time).
     void trim(uint64_t keep_bytes) {
+        const uint64_t asked = need;
+        need = 0;  // (a call that never touches this buffer -- the device-resident path shares the pool -- counts as a small one)
         if (cap <= keep_bytes) return;
-        if (need > keep_bytes) { small_calls = 0; return; }
+        if (asked > keep_bytes) { small_calls = 0; return; }
         if (++small_calls >= 8u) { free(); small_calls = 0; }
     }
     void free() {
@@ -264,6 +300,17 @@ int lane_lab_device(int device, uint32_t mode, uint32_t p0, uint32_t p1, uint32_
     if ((mode == 1u || mode == 2u) && p0 != 1u && p0 != 2u && p0 != 4u) { err = "lane lab: 1, 2 or 4 slots per lane"; return ERR_ARG; }
     if (mode == 2u && (p1 == 0u || p1 > 64u * p0)) { err = "lane lab: ef beyond the result set"; return ERR_ARG; }
     if (mode == 3u && (p0 < 4u || p0 > 12u || p2 > 13u || p1 > 31u || p1 + 3u < p0 || p1 - (p0 - 3u) != p2)) { err = "lane lab: table geometry"; return ERR_ARG; }
+    // the script is checked here, before anything reaches the device: an op that names a lane set the caller did not pass would
+    // read device memory out of bounds (LAB_PUSH_LANES / LAB_MERGE / LAB_BATCH take the set's index in their last word)
+    if (n_ops != 0u && ops == nullptr) { err = "lane lab: null script"; return ERR_ARG; }
+    if (n_lane_sets != 0u && lanes == nullptr) { err = "lane lab: null lane sets"; return ERR_ARG; }
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const uint32_t op = ops[4u * i], c = ops[4u * i + 3u];
+        if ((op == LAB_PUSH_LANES || op == LAB_MERGE || op == LAB_BATCH) && c >= n_lane_sets) {
+            err = "lane lab: op " + std::to_string(i) + " names lane set " + std::to_string(c) + " of " + std::to_string(n_lane_sets);
+            return ERR_ARG;
+        }
+    }
     DeviceGuard on_device(device);
     HIP_TRY(on_device.status());
     const uint32_t scratch_cap = 1u << 16;
@@ -275,6 +322,7 @@ int lane_lab_device(int device, uint32_t mode, uint32_t p0, uint32_t p1, uint32_
     HIP_TRY(d_scratch.ensure((uint64_t)scratch_cap * sizeof(hent_t)));
     if (n_ops) HIP_TRY(hipMemcpy(d_ops.p, ops, (size_t)n_ops * 16, hipMemcpyHostToDevice));
     if (n_lane_sets) HIP_TRY(hipMemcpy(d_lanes.p, lanes, (size_t)n_lane_sets * 512, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(d_lanes.p, 0, 512));
     HIP_TRY(hipMemset(d_out.p, 0, (size_t)out_words * 4));
     LaneLabArgs a{};
     a.ops = d_ops.as<uint32_t>();
@@ -298,18 +346,33 @@ int gather_sharded_answers(const int* devices, int n_shards, const uint64_t* nq_
     DeviceGuard on_root(root_device);
     HIP_TRY(on_root.status());
     hipStream_t stream = static_cast<hipStream_t>(root_stream);
+    // sizes first: nothing is copied when a product does not fit (the offsets below are row * k * 8 bytes at most)
+    uint64_t total = 0;
+    for (int s = 0; s < n_shards; ++s) {
+        if (nq_shard[s] > UINT64_MAX - total) { err = "gather: the shards' query counts overflow"; return ERR_ARG; }
+        total += nq_shard[s];
+    }
+    if (k != 0 && total > (UINT64_MAX / sizeof(uint64_t)) / k) { err = "gather: nq * k * 8 bytes overflows"; return ERR_ARG; }
+    // an error part-way leaves earlier copies in flight on the caller's stream: they are waited for before the caller may free
+    // or reuse the root arrays (whatever the copy that failed returned is what is reported)
+    auto fail = [&](hipError_t e) {
+        (void)hipStreamSynchronize(stream);
+        err = std::string("HIP: ") + hipGetErrorString(e);
+        return ERR_DEVICE;
+    };
     uint64_t row = 0;  // first query of shard s in input order
     for (int s = 0; s < n_shards; ++s) {
         const uint64_t cnt = nq_shard[s];
         if (cnt == 0) continue;
         const int src = devices[s];
-        HIP_TRY(hipMemcpyPeerAsync(root_ids + row * k, root_device, d_ids[s], src, cnt * k * sizeof(uint64_t), stream));
-        HIP_TRY(hipMemcpyPeerAsync(root_dists + row * k, root_device, d_dists[s], src, cnt * k * sizeof(float), stream));
-        if (root_layer && d_layer && d_layer[s])
-            HIP_TRY(hipMemcpyPeerAsync(root_layer + row * k, root_device, d_layer[s], src, cnt * k * sizeof(uint8_t), stream));
-        if (root_rank && d_rank && d_rank[s])
-            HIP_TRY(hipMemcpyPeerAsync(root_rank + row * k, root_device, d_rank[s], src, cnt * k * sizeof(int32_t), stream));
-        HIP_TRY(hipMemcpyPeerAsync(root_counts + row, root_device, d_counts[s], src, cnt * sizeof(uint32_t), stream));
+        hipError_t e = hipMemcpyPeerAsync(root_ids + row * k, root_device, d_ids[s], src, cnt * k * sizeof(uint64_t), stream);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(root_dists + row * k, root_device, d_dists[s], src, cnt * k * sizeof(float), stream);
+        if (e == hipSuccess && root_layer && d_layer && d_layer[s])
+            e = hipMemcpyPeerAsync(root_layer + row * k, root_device, d_layer[s], src, cnt * k * sizeof(uint8_t), stream);
+        if (e == hipSuccess && root_rank && d_rank && d_rank[s])
+            e = hipMemcpyPeerAsync(root_rank + row * k, root_device, d_rank[s], src, cnt * k * sizeof(int32_t), stream);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(root_counts + row, root_device, d_counts[s], src, cnt * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return fail(e);
         row += cnt;
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -489,7 +552,7 @@ int DeviceIndex::run_exact(Workspace& w, const float* d_qpad, const uint32_t* d_
         HIP_TRY(w.bitmap.ensure((uint64_t)grid * bm_slice));
         HIP_TRY(w.heaps.ensure((uint64_t)grid * heap_stride * sizeof(hent_t)));
         HIP_TRY(w.retry[0].ensure((uint64_t)nq * sizeof(uint32_t)));
-        if (std::getenv("HNSWGPU_TRACE_LAUNCH"))
+        if (knobs().trace_launch)
             std::fprintf(stderr, "[hnswgpu launch] literal kernel, pass %d: %u queries on %u workgroups (%d per CU), %zu bytes of LDS each "
                          "(candidate heap: %u entries in LDS, %llu in all)\n", pass, work, grid, per_cu, lds, x.cand_lds, (unsigned long long)cand_cap);
         SearchArgs a{};
@@ -647,10 +710,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (adapt_ef_ == ef && adapt_tbits_ != 0) tbits = adapt_tbits_;
     }
     bool env_forced = false;
-    if (const char* e = std::getenv("HNSWGPU_HASH_BITS")) {  // tuning / test hook: initial table size
-        int b = std::atoi(e);
-        if (b >= 6 && b <= 14) { tbits = (uint32_t)b; env_forced = true; }
-    }
+    const Knobs& kn = knobs();  // (the environment was read once: search_device.hpp)
+    if (kn.hash_bits >= 6 && kn.hash_bits <= 14) { tbits = (uint32_t)kn.hash_bits; env_forced = true; }  // tuning / test hook: initial table size
     const uint32_t tbits_first = tbits;
     const size_t lds_fixed = tile_bytes + IDS_BYTES;
     int table = TABLE_LDS_CELL16;
@@ -658,7 +719,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
 
     // Batch scheduling: the searches run in descending order of the distance to the layer-0 entry point (the descent's
     // result), long searches first (DESIGN.md "scheduling").  Small batches skip it (one launch less, lowest latency).
-    const bool scheduled = nq >= 256 && !std::getenv("HNSWGPU_NO_SCHED");
+    const bool scheduled = nq >= 256 && !kn.no_sched;
     if (scheduled) {
         HIP_TRY(w.order.ensure(nq * sizeof(uint32_t)));
         HIP_TRY(kernel_set(kernel_metric()).launch_order(stream, w.pre.as<PreDescent>(), (uint32_t)nq, w.order.as<uint32_t>()));
@@ -689,21 +750,21 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         a.nrm2 = static_cast<const double*>(d_nrm2_);
         a.idbits = idbits;
         const KernelSet& ks = kernel_set(kernel_metric());
-        const bool strict_kernel = strict_ties && table != TABLE_GLOBAL_BITMAP && !std::getenv("HNSWGPU_NO_INKERNEL");
+        const bool strict_kernel = strict_ties && table != TABLE_GLOBAL_BITMAP && !kn.no_inkernel;
         if (slots <= (strict_kernel ? HNSW_MERGE_SMAX : HNSW_MERGE_LEAN_SMAX)) {  // merge_list's scatter buffer
             a.merge_entries = (uint32_t)slots * 64u + 64u;
             lds += (size_t)a.merge_entries * sizeof(hent_t);
         }
         int per_cu = 0;
         int strict_cap = STRICT_WG_PER_CU;
-        if (const char* e = std::getenv("HNSWGPU_STRICT_WG_PER_CU")) strict_cap = std::max(1, std::atoi(e));  // tuning hook
+        if (kn.strict_wg_per_cu > 0) strict_cap = kn.strict_wg_per_cu;  // tuning hook (reported by HNSWGPU_TRACE_LAUNCH)
         if (strict_kernel) {
             // top levels of the (lazy) literal candidate heap, for the few pops that need it: 512 entries when that costs no
             // resident wave (the strict kernel sits at 4 waves per SIMD by its registers, which leaves ~10 KB of LDS per
             // wave), else 256 -- a replay touches the heap ~800 times per query, every level out of LDS is an L2 round trip
             a.cand_lds = 256;
-            if (const char* e = std::getenv("HNSWGPU_CAND_LDS")) {
-                a.cand_lds = (uint32_t)std::max(0, std::min(4096, std::atoi(e)));  // tuning hook
+            if (kn.cand_lds >= 0) {
+                a.cand_lds = (uint32_t)std::min(4096, kn.cand_lds);  // tuning hook
             } else {
                 int occ256 = 0, occ512 = 0;
                 HIP_TRY(ks.occupancy(slots, table, true, lds + 256 * sizeof(hent_t), &occ256));
@@ -719,11 +780,11 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         // fit 20 workgroups per CU; measured (config 2, one box) 7.63 M queries/s at 20, 8.49 M at 16.  The lean kernel gains
         // from its 20 (9.7 M) and keeps them.
         if (strict_kernel) per_cu = std::min(per_cu, strict_cap);
-        if (const char* e = std::getenv("HNSWGPU_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // tuning hook
+        if (kn.waves_per_cu > 0) per_cu = std::max(1, std::min(per_cu, kn.waves_per_cu));  // tuning hook
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
-        if (std::getenv("HNSWGPU_TRACE_LAUNCH"))  // diagnostics: what bounds the resident workgroups of this launch
-            std::fprintf(stderr, "[hnswgpu launch] %u queries, %d workgroups per CU, %zu bytes of LDS each (literal heap: %u entries), table 2^%u cells, strict %d\n",
-                         work, per_cu, lds, a.cand_lds, a.tbits, (int)strict_kernel);
+        if (kn.trace_launch)  // diagnostics: what bounds the resident workgroups of this launch
+            std::fprintf(stderr, "[hnswgpu launch] %u queries, %d workgroups per CU (strict cap %d), %zu bytes of LDS each (literal heap: %u entries), table 2^%u cells, strict %d\n",
+                         work, per_cu, strict_cap, lds, a.cand_lds, a.tbits, (int)strict_kernel);
         a.queries = w.qpad.as<float>();
         a.qlist = qlist;
         a.nq = work;
@@ -763,7 +824,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             a.cand_cap = cap;
             a.oplog = w.oplog.as<hent_t>();
             a.oplog_cap = cap;
-            if (const char* e = std::getenv("HNSWGPU_EXACT_FIRST")) a.exact_first = std::atoi(e) != 0 ? 1u : 0u;  // test hook
+            if (kn.exact_first >= 0) a.exact_first = kn.exact_first != 0 ? 1u : 0u;  // test hook
         }
         // (the first launch finds the counters zeroed by the descent kernel; the flagged list spans relaunches)
         if (launches != 0) HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, 16, stream));
@@ -936,7 +997,7 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     // while it pads them (the H2D copy disappears into a pass that runs anyway), and the search kernels write the answers --
     // ids | dists | rank | layer | counts, 1.7 MB for 10 000 x 10 -- straight into a pinned arena the sink reads.  (Rounds 2-3:
     // gather -> H2D copy -> pad kernel ... -> D2H copy, every step waiting for the one before.)
-    const bool trace = std::getenv("HNSWGPU_TRACE_HOST") != nullptr;
+    const bool trace = knobs().trace_host;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -973,8 +1034,8 @@ int DeviceIndex::search_host_staged(const float* queries, const float* const* ro
     // (measured, tools/host_call_sweep.py: 2 chunks beat 4 and 1 -- every chunk is a launch of the descent kernel, whose reads across
     // PCIe are what the front of the call waits for, not the gather; 4 to 8 threads are equal, more are slower)
     uint64_t max_threads = 8, max_chunks = 2;
-    if (const char* e = std::getenv("HNSWGPU_HOST_THREADS")) max_threads = (uint64_t)std::max(1, std::atoi(e));  // tuning hooks
-    if (const char* e = std::getenv("HNSWGPU_HOST_CHUNKS")) max_chunks = (uint64_t)std::max(1, std::atoi(e));
+    if (knobs().host_threads > 0) max_threads = (uint64_t)knobs().host_threads;  // tuning hooks
+    if (knobs().host_chunks > 0) max_chunks = (uint64_t)knobs().host_chunks;
     const unsigned nt = total_bytes < (256u << 10) || max_threads == 1 ? 1u
                         : (unsigned)std::min<uint64_t>(max_threads, std::max<uint64_t>(2, total_bytes / (256u << 10)));
     const uint64_t n_chunks = nt == 1 ? 1 : std::min<uint64_t>(max_chunks, std::max<uint64_t>(1, nq / 1024));

@@ -14,6 +14,25 @@ namespace hnswgpu {
 
 constexpr int ARITH_SCALAR = 0, ARITH_SIMD8 = 1;  // DeviceIndex::set_arithmetic
 
+// The HNSWGPU_* tuning / test hooks.  The environment is read ONCE per process (at the first use) -- not on every launch --
+// and again only when the caller says it changed it (hnswgpu_reload_env; the tests do).  -1 / false: not set.
+struct Knobs {
+    int hash_bits = -1;          // HNSWGPU_HASH_BITS: initial visited-table size (6..14)
+    bool no_sched = false;       // HNSWGPU_NO_SCHED: searches in input order
+    bool no_inkernel = false;    // HNSWGPU_NO_INKERNEL: strict ties resolved by the literal kernel only
+    int strict_wg_per_cu = -1;   // HNSWGPU_STRICT_WG_PER_CU
+    int cand_lds = -1;           // HNSWGPU_CAND_LDS
+    int waves_per_cu = -1;       // HNSWGPU_WAVES_PER_CU
+    int exact_first = -1;        // HNSWGPU_EXACT_FIRST (test hook)
+    bool trace_launch = false;   // HNSWGPU_TRACE_LAUNCH
+    bool trace_host = false;     // HNSWGPU_TRACE_HOST
+    int host_threads = -1;       // HNSWGPU_HOST_THREADS
+    int host_chunks = -1;        // HNSWGPU_HOST_CHUNKS
+    bool ffi_unpack = false;     // HNSWGPU_FFI_UNPACK
+};
+const Knobs& knobs();
+void reload_knobs();
+
 // Plain-pointer view handed to the kernels by value.
 struct DeviceIndexView {
     const float* vec;          // [n][row_stride] f32, rows zero-padded to 128-byte lines

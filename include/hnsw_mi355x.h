@@ -264,6 +264,12 @@ int hnswgpu_search_batch_end(hnswgpu_ticket* ticket);
 int hnswgpu_set_strict_ties(hnswgpu_index* idx, int on);
 int hnswgpu_last_tie_count(const hnswgpu_index* idx, uint32_t* ties);
 
+/* The HNSWGPU_* tuning and test hooks (HNSWGPU_HASH_BITS, _NO_SCHED, _NO_INKERNEL, _STRICT_WG_PER_CU, _CAND_LDS, _WAVES_PER_CU,
+ * _EXACT_FIRST, _TRACE_LAUNCH, _TRACE_HOST, _HOST_THREADS, _HOST_CHUNKS, _FFI_UNPACK) are read from the environment ONCE per
+ * process, at the library's first search -- never on the launch path.  A caller that changes them afterwards (the tests do)
+ * says so with this call.  Always HNSWGPU_OK.                                                                          */
+int hnswgpu_reload_env(void);
+
 /* The arithmetic of Distance<f32>::eval during SEARCH (construction always sums like the scalar build).
  *   HNSWGPU_ARITH_SCALAR (default): the crate's default build -- every sum left to right over the vector index
  *                                   (anndists 0.1 without features, Cargo.toml:104-106); what the parity tests pin.

@@ -31,6 +31,23 @@ def native():
     return H
 
 
+@pytest.fixture
+def knob(monkeypatch):
+    """knob(name, value) / knob(name, None): sets / removes an HNSWGPU_* hook in the environment and tells the library, which reads
+    the environment once per process and otherwise only on hnswgpu_reload_env; both are undone when the test ends."""
+    import hnsw_rs_amd as H
+
+    def set_(name, value=None):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+        H.reload_env()
+    yield set_
+    monkeypatch.undo()
+    H.reload_env()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

@@ -127,21 +127,21 @@ def test_sqrt_correctly_rounded(native):
 
 
 @pytest.mark.parametrize("bits", [6, 8, 10])
-def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, monkeypatch):
+def test_visited_table_overflow_is_exact(native, oracle, tmp_path, bits, knob):
     """A visited table far too small for the query must not change results: a query that outgrows its
     LDS table starts over, inside the same launch, on the exact HBM bitmap (HNSWGPU_HASH_BITS is a
     test/tuning hook that forces a tiny table)."""
     X, o, h = build_pair(native, oracle, tmp_path, 4000, 32, 16, 100, "DistL2", seed=21)
     Q = uniform(300, 32, 22)
     ref = o.parallel_search(Q, 10, 100)
-    monkeypatch.setenv("HNSWGPU_HASH_BITS", str(bits))
+    knob("HNSWGPU_HASH_BITS", str(bits))
     res = h.parallel_search_flat(Q, 10, 100)
     assert_same(res, ref)
     ms, launches = h.last_kernel_ms()
     assert launches >= 1
 
 
-def test_batch_scheduling_and_exact_first_do_not_change_answers(native, oracle, tmp_path, monkeypatch):
+def test_batch_scheduling_and_exact_first_do_not_change_answers(native, oracle, tmp_path, knob):
     """Batches of >= 256 queries are searched longest-first (estimate + ordering kernels); HNSWGPU_NO_SCHED turns
     that off, HNSWGPU_EXACT_FIRST=1 answers every query with the literal heaps from the start (what the library does
     by itself when most queries of the previous batch met a tie).  Same answers as the oracle in every mode."""
@@ -149,10 +149,10 @@ def test_batch_scheduling_and_exact_first_do_not_change_answers(native, oracle, 
     Q = uniform(700, 48, 34)
     ref = o.parallel_search(Q, 10, 64)
     assert_same(h.parallel_search_flat(Q, 10, 64), ref)
-    monkeypatch.setenv("HNSWGPU_NO_SCHED", "1")
+    knob("HNSWGPU_NO_SCHED", "1")
     assert_same(h.parallel_search_flat(Q, 10, 64), ref)
-    monkeypatch.delenv("HNSWGPU_NO_SCHED")
-    monkeypatch.setenv("HNSWGPU_EXACT_FIRST", "1")
+    knob("HNSWGPU_NO_SCHED", None)
+    knob("HNSWGPU_EXACT_FIRST", "1")
     assert_same(h.parallel_search_flat(Q, 10, 64), ref)
     assert h.last_tie_count() <= 700
 

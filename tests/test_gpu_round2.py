@@ -270,7 +270,7 @@ def _clustered(n, d, seed):
     return (centres[c] + 0.1 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
 
 
-def _full_size_case(native, oracle, tmp_path, monkeypatch, n, d, m, efc, k, ef, nq, n_dup):
+def _full_size_case(native, oracle, tmp_path, knob, n, d, m, efc, k, ef, nq, n_dup):
     X = _clustered(n, d, 0x5EED0001)
     if n_dup:  # exact duplicates (distinct ids): queries near them meet equal f32 distances for certain
         rng = np.random.default_rng(3)
@@ -291,26 +291,26 @@ def _full_size_case(native, oracle, tmp_path, monkeypatch, n, d, m, efc, k, ef, 
     ties = h.last_tie_count()
     # every query through the literal candidate heap (hand-over at the first pop) and, where equal distances reach the
     # answer, the literal result heap: same answers
-    monkeypatch.setenv("HNSWGPU_EXACT_FIRST", "1")
+    knob("HNSWGPU_EXACT_FIRST", "1")
     assert_same(h.parallel_search_flat(Q, k, ef), ref)
-    monkeypatch.delenv("HNSWGPU_EXACT_FIRST")
+    knob("HNSWGPU_EXACT_FIRST", None)
     # a visited table far too small: most queries migrate to the HBM bitmap (n / 8 bytes per slice) mid-search
-    monkeypatch.setenv("HNSWGPU_HASH_BITS", "8")
+    knob("HNSWGPU_HASH_BITS", "8")
     assert_same(h.parallel_search_flat(Q[:1500], k, ef), oracle.SearchResult(ref.ids[:1500], ref.dists[:1500], ref.layers[:1500], ref.ranks[:1500], ref.counts[:1500]))
-    monkeypatch.delenv("HNSWGPU_HASH_BITS")
+    knob("HNSWGPU_HASH_BITS", None)
     return ties
 
 
-def test_full_size_parity_200k_x_128(native, oracle, tmp_path, monkeypatch):
+def test_full_size_parity_200k_x_128(native, oracle, tmp_path, knob):
     """BASELINE config 2's shape at 200 000 points (18 id bits: the 16-bit visited cells hold 5 + 11 bits, bitmap slices
     of 25 KB), product-built graph, 4 000 queries, with duplicated points so that tie handling is exercised at scale."""
-    ties = _full_size_case(native, oracle, tmp_path, monkeypatch, 200_000, 128, 16, 200, 10, 64, 4000, 2000)
+    ties = _full_size_case(native, oracle, tmp_path, knob, 200_000, 128, 16, 200, 10, 64, 4000, 2000)
     assert ties > 0
 
 
-def test_full_size_parity_config5_60k_x_784(native, oracle, tmp_path, monkeypatch):
+def test_full_size_parity_config5_60k_x_784(native, oracle, tmp_path, knob):
     """BASELINE config 5 at its real size: 60 000 x 784, M = 32 (64 ids per row), ef = 200 (4 result slots per lane)."""
-    _full_size_case(native, oracle, tmp_path, monkeypatch, 60_000, 784, 32, 400, 10, 200, 2000, 600)
+    _full_size_case(native, oracle, tmp_path, knob, 60_000, 784, 32, 400, 10, 200, 2000, 600)
 
 
 # ------------------------------------------------------------------------------------------------- construction

@@ -55,7 +55,7 @@ from test_gpu_parity import assert_same  # noqa: E402
 from test_gpu_round2 import _clustered  # noqa: E402
 
 
-def _full_size(native, oracle, tmp_path, monkeypatch, n, d, m, efc, dist, k, ef, nq, n_dup, n_small_table, normalize=False):
+def _full_size(native, oracle, tmp_path, knob, n, d, m, efc, dist, k, ef, nq, n_dup, n_small_table, normalize=False):
     """BASELINE config at its REAL size: GPU-assisted build (the product's) -> hnswio dump -> product reload + upload and
     oracle reload of the same files -> the same queries through both: ids, f32 distance bits, p_ids, counts identical --
     strict as shipped, then with every pop taken from the literal candidate heap, then with a visited table far too small."""
@@ -82,31 +82,31 @@ def _full_size(native, oracle, tmp_path, monkeypatch, n, d, m, efc, dist, k, ef,
     res = h.parallel_search_flat(Q, k, ef)
     assert_same(res, ref)
     ties = h.last_tie_count()
-    monkeypatch.setenv("HNSWGPU_EXACT_FIRST", "1")
+    knob("HNSWGPU_EXACT_FIRST", "1")
     assert_same(h.parallel_search_flat(Q, k, ef), ref)
-    monkeypatch.delenv("HNSWGPU_EXACT_FIRST")
-    monkeypatch.setenv("HNSWGPU_HASH_BITS", "8")
+    knob("HNSWGPU_EXACT_FIRST", None)
+    knob("HNSWGPU_HASH_BITS", "8")
     s = n_small_table
     assert_same(h.parallel_search_flat(Q[:s], k, ef), oracle.SearchResult(ref.ids[:s], ref.dists[:s], ref.layers[:s], ref.ranks[:s], ref.counts[:s]))
-    monkeypatch.delenv("HNSWGPU_HASH_BITS")
+    knob("HNSWGPU_HASH_BITS", None)
     return ties
 
 
-def test_full_size_parity_config2_1m_x_128(native, oracle, tmp_path, monkeypatch):
+def test_full_size_parity_config2_1m_x_128(native, oracle, tmp_path, knob):
     """BASELINE config 2 itself: 1M x 128 L2, M=16, ef_c=200, ef=64, 10 000 clustered queries (20 id bits, 125-KB bitmap slices)."""
-    ties = _full_size(native, oracle, tmp_path, monkeypatch, 1_000_000, 128, 16, 200, "DistL2", 10, 64, 10_000, 2000, 1500)
+    ties = _full_size(native, oracle, tmp_path, knob, 1_000_000, 128, 16, 200, "DistL2", 10, 64, 10_000, 2000, 1500)
     assert ties > 0
 
 
-def test_full_size_parity_config3_cosine_1m2_x_25(native, oracle, tmp_path, monkeypatch):
+def test_full_size_parity_config3_cosine_1m2_x_25(native, oracle, tmp_path, knob):
     """BASELINE config 3 itself: 1.2M x 25 DistCosine, M=24, ef=128 (two result slots per lane; 21 id bits; every point's f64
     norm inside its own 128-byte row)."""
-    _full_size(native, oracle, tmp_path, monkeypatch, 1_200_000, 25, 24, 400, "DistCosine", 10, 128, 4000, 2000, 1000)
+    _full_size(native, oracle, tmp_path, knob, 1_200_000, 25, 24, 400, "DistCosine", 10, 128, 4000, 2000, 1000)
 
 
-def test_full_size_parity_config3_dot_1m2_x_25(native, oracle, tmp_path, monkeypatch):
+def test_full_size_parity_config3_dot_1m2_x_25(native, oracle, tmp_path, knob):
     """Config 3 the way the reference runs it: DistDot on L2-normalised vectors (examples/ann-glove25-angular.rs:81-82, :107-108)."""
-    _full_size(native, oracle, tmp_path, monkeypatch, 1_200_000, 25, 24, 400, "DistDot", 10, 128, 4000, 2000, 1000, normalize=True)
+    _full_size(native, oracle, tmp_path, knob, 1_200_000, 25, 24, 400, "DistDot", 10, 128, 4000, 2000, 1000, normalize=True)
 
 
 # ------------------------------------------------------------------------------------------------- DistCosine: norm inside the row

@@ -257,7 +257,7 @@ def _ffi_answers(lib, res, nq):
     return out
 
 
-def test_ffi_answers_written_in_place_equal_the_unpacked_ones(native, oracle, tmp_path, monkeypatch):
+def test_ffi_answers_written_in_place_equal_the_unpacked_ones(native, oracle, tmp_path, knob, monkeypatch):
     """parallel_search_neighbours_f32 (src/libext.rs:205-254): the search kernels write ids, distances and counts straight into
     the Neighbour_api / Neighbourhood_api records of a page-locked slab (no unpacking pass).  The records equal the oracle's
     answers and those of the unpacking path (HNSWGPU_FFI_UNPACK=1: ordinary memory filled from the pinned arena); a freed slab
@@ -309,11 +309,11 @@ def test_ffi_answers_written_in_place_equal_the_unpacked_ones(native, oracle, tm
     assert _ffi_answers(lib, res, 64) == expect(12, 1100, 64)
     lib.hnswgpu_free_neighbourhood_vec(res)
     # the unpacking path gives the same records
-    monkeypatch.setenv("HNSWGPU_FFI_UNPACK", "1")
+    knob("HNSWGPU_FFI_UNPACK", "1")
     res = lib.parallel_search_neighbours_f32(api, nq, d, ptrs, 7, 40)
     assert _ffi_answers(lib, res, nq) == want
     lib.hnswgpu_free_neighbourhood_vec(res)
-    monkeypatch.delenv("HNSWGPU_FFI_UNPACK")
+    knob("HNSWGPU_FFI_UNPACK", None)
     # answers that are never freed: beyond 256 MB of page-locked slabs the library hands out ordinary memory, still correct
     big_q = 4000
     Qb = np.tile(Q, (6, 1))[:big_q].copy()
