@@ -45,6 +45,10 @@ CONFIGS = {
                         label="GloVe-25-shape synthetic 1.2Mx25 f32, L2-normalised, DistDot M=24 ef=128"),
     "mnist784": dict(n=60_000, d=784, dist="DistL2", M=32, efc=400, k=10, ef=200, nq=10_000, nq_multi=10_000, nq_total_multi=80_000,
                      label="MNIST-784-shape synthetic 60kx784 f32 L2 M=32 ef=200"),
+    # BASELINE config 5's shape with four times the points: 753 MB of vectors, beyond the 256 MiB Infinity Cache -- the line whose
+    # roofline fraction is an HBM number (config 5 itself, 188 MB, is served by the cache: its line says so)
+    "mnist784_hbm": dict(n=240_000, d=784, dist="DistL2", M=32, efc=400, k=10, ef=200, nq=10_000, nq_multi=10_000, nq_total_multi=80_000,
+                         label="MNIST-784-shape synthetic 240kx784 f32 L2 M=32 ef=200 (config 5's shape, 4 x the points: out of the Infinity Cache)"),
     "random10k": dict(n=10_000, d=25, dist="DistL2", M=15, efc=200, k=10, ef=24, nq=1_000, nq_multi=1_000, nq_total_multi=8_000,
                       label="random.rs shape 10kx25 f32 L2 M=15 ef=24"),
 }

@@ -190,6 +190,7 @@ int orc_parallel_search_filter(void* hv, const float* queries, size_t nq, size_t
 // The optimised flat-array CPU baseline (flat_baseline.hpp; timing only, never a parity check): built from a loaded index.
 void* orc_flat_new(void* hv) {
     ORC_TRY
+    oracle_pin::InterleavedAllocations spread;  // (one thread builds the arrays every search thread of both sockets will read)
     return new FlatBaseline(*static_cast<Hnsw*>(hv));
     ORC_CATCH(nullptr)
 }
@@ -223,6 +224,7 @@ int orc_file_dump(void* hv, const char* dir, const char* basename) {
 // HnswIo::new(dir, basename).load_hnsw::<f32, D>()
 void* orc_load(const char* dir, const char* basename, int dist) {
     ORC_TRY
+    oracle_pin::InterleavedAllocations spread;  // (likewise: the points and their lists are allocated by this one thread)
     return load_hnsw(dir, basename, (DistKind)dist).release();
     ORC_CATCH(nullptr)
 }

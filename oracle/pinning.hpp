@@ -4,6 +4,10 @@
 // run on T threads uses as few memory domains as T allows and the by-thread-count figures are reproducible.
 #pragma once
 #include <sched.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+
+#include <cstdlib>
 
 #include <atomic>
 #include <cstdio>
@@ -11,6 +15,36 @@
 #include <vector>
 
 namespace oracle_pin {
+
+// The index of the CPU baseline is built by ONE thread (orc_load, FlatBaseline's constructor); with the kernel's default
+// first-touch policy every page of it then lives on that thread's NUMA node, and the 128-256 search threads of a two-socket
+// host all pull from one node's memory controllers (round 5: the baseline got SLOWER beyond 64 threads).  While an
+// InterleavedAllocations object lives, the pages this thread touches for the first time are spread round-robin over all
+// nodes (set_mempolicy(MPOL_INTERLEAVE), the raw system call: no libnuma in the image); ORACLE_NO_INTERLEAVE=1 keeps the default.
+struct InterleavedAllocations {
+    bool on = false;
+    InterleavedAllocations() {
+#if defined(__linux__) && defined(__x86_64__)
+        if (std::getenv("ORACLE_NO_INTERLEAVE")) return;
+        int nodes = 0;
+        for (; nodes < 64; ++nodes) {
+            char path[96];
+            std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d", nodes);
+            if (::access(path, F_OK) != 0) break;
+        }
+        if (nodes < 2) return;
+        unsigned long mask = nodes >= 64 ? ~0ul : ((1ul << nodes) - 1ul);
+        on = ::syscall(238 /* SYS_set_mempolicy */, 3 /* MPOL_INTERLEAVE */, &mask, (unsigned long)(nodes + 1)) == 0;
+#endif
+    }
+    ~InterleavedAllocations() {
+#if defined(__linux__) && defined(__x86_64__)
+        if (on) (void)::syscall(238, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+#endif
+    }
+    InterleavedAllocations(const InterleavedAllocations&) = delete;
+    InterleavedAllocations& operator=(const InterleavedAllocations&) = delete;
+};
 
 inline std::atomic<int>& mode() {
     static std::atomic<int> m{0};
