@@ -141,6 +141,33 @@ def numa_nodes():
     return out
 
 
+def cpu_budget():
+    """(logical CPUs visible, CPUs' worth of time this process may use, where that number comes from).  A container shows every
+    logical CPU of its host but may be held to a CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us): threads beyond the quota
+    are throttled, not run -- Rayon's default pool (std::thread::available_parallelism) honours the quota too."""
+    logical = os.cpu_count() or 1
+    usable, source = logical, "all logical CPUs"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < usable:
+            usable, source = aff, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(quota) > 0 and -(-int(quota) // int(period)) < usable:
+            usable, source = -(-int(quota) // int(period)), f"cgroup v2 cpu.max = {quota} {period}"
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and -(-quota // period) < usable:
+                usable, source = -(-quota // period), f"cgroup v1 cfs quota {quota} / {period}"
+        except (OSError, ValueError):
+            pass
+    return logical, max(1, usable), source
+
+
 def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cnt, cpu_seconds, orc=None):
     """Times the oracle (CPU restatement of the reference, test infrastructure) on the same graph and queries and
     compares the device answers with it.  Returns (cpu_baseline, parity) for the bench line.
@@ -148,7 +175,7 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     for about `cpu_seconds` of CPU work in total."""
     import oracle_lib
     nq_local = Q.shape[0]
-    cores = os.cpu_count() or 1
+    logical, cores, budget_source = cpu_budget()  # cores: what this process may actually use (the box of round 5 showed 256, granted 16)
     if orc is None:
         t0 = time.time()
         orc = oracle_lib.OracleHnsw.load(cache_dir, base, dist)
@@ -161,7 +188,8 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
     # sockets and the rate FALLS with the thread count, so 32 / 64 / 128 / 256 threads (and all logical CPUs) are timed, each
     # worker pinned to its own logical CPU, NUMA node by NUMA node (oracle/pinning.hpp: T threads then span as few memory
     # domains as T allows), plus the unpinned run on all CPUs and on a quarter of them; the best rate is reported.
-    threads = sorted({t for t in (32, 64, 128, 256) if t <= cores} | {cores}, reverse=True)
+    # (thread counts around the CPU budget: a quarter, half, all of it, and twice it -- what an oversubscribed pool costs)
+    threads = sorted({max(1, cores // 4), max(1, cores // 2), cores, min(logical, 2 * cores)}, reverse=True)
     unpinned_threads = sorted({cores, max(1, cores // 4)}, reverse=True)
     # ~6 runs each of: the pinned thread counts, two SIMD-order ones, two unpinned ones: size the sample for the budget
     sample = int(min(nq_local, max(probe, rate * cpu_seconds / (6.0 * (len(threads) + 4)))))
@@ -233,7 +261,8 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
                     "placement": placement,
                     "pinning": "by_threads / by_threads_simd_order: worker t pinned to the t-th logical CPU, NUMA node by NUMA node "
                                "(oracle/pinning.hpp; first CPUs: %s); by_threads_unpinned: the scheduler's placement" % [oracle_lib.OracleHnsw.pinning_cpu(t) for t in (0, 1, 2, 3)],
-                    "numa_nodes": numa_nodes(), "logical_cpus": cores,
+                    "numa_nodes": numa_nodes(), "logical_cpus": logical, "usable_cpus": cores, "usable_cpus_from": budget_source,
+                    "index_pages": "interleaved over the NUMA nodes while one thread loads the index (oracle/pinning.hpp: set_mempolicy)",
                     "allocator": "glibc malloc (per-thread arenas) -- also what a Rust binary uses by default (std's System allocator)",
                     "flat_avx": {"value": round(flat_trials[flat_threads], 1), "cores": flat_threads,
                                  "by_threads": {str(t): round(v, 1) for t, v in flat_trials.items()},
@@ -242,7 +271,7 @@ def cpu_baseline_leg(cache_dir, base, dist, Q, k, ef, res_ids, res_dists, st, cn
                                          "an optimised CPU implementation, not the reference's data model"},
                     "sample": f"first {sample} of the same {nq_local} queries (flat variant: {flat_sample}), same graph (reloaded from the "
                               f"same hnswio dump), oracle parallel_search (Rayon-style worker threads; best of {threads} pinned / {unpinned_threads} unpinned threads on a "
-                              f"{cores}-core host, scalar and SIMD-order distances)"}
+                              f"{logical}-CPU host that grants this process {cores} CPUs ({budget_source}), scalar and SIMD-order distances)"}
     del orc
     return cpu_baseline, parity
 
