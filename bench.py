@@ -414,9 +414,9 @@ def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, cpu_queries, pct
              "frac_of_hbm_peak": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "reference_panics": int(panics.value)}
         if orc is not None and cpu_queries > 0:
             m = min(nq, cpu_queries)
-            cores = os.cpu_count() or 1
+            _, cores, _ = cpu_budget()  # (the CPUs this process is granted, not the ones it can see)
             best = None
-            for nt in sorted({cores, max(1, cores // 4)}):
+            for nt in sorted({cores, min(os.cpu_count() or 1, 2 * cores)}):
                 r = orc.parallel_search_filter(Q[:m], k, ef, allowed, nt)
                 if best is None or r.elapsed_s < best[0]:
                     best = (r.elapsed_s, nt, r)
