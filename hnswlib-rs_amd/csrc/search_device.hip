@@ -698,6 +698,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     int slots = 1;
     while ((uint64_t)slots * 64 < ef) slots *= 2;
     if (slots == 8) slots = 16;  // kernels are instantiated for 1, 2, 4 and 16 result slots per lane
+    // Lists of more than 64 ids (M > 32: none of BASELINE's configs) need a loop over the batches of a list; only the
+    // 16-slot kernels carry it -- in the others the single batch is a compile-time fact, worth 1.5-4 % to every search.
+    if (v_.deg_stride > 64u) slots = 16;
 
     // Visited-set sizing.  LDS per wavefront is what bounds occupancy, so the table is sized for the
     // typical query (ef x degree cells, ~2.4x the median number of visited points, measured); the few
