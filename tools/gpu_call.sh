@@ -72,8 +72,8 @@ PY
     stamp "GPU suite"
     timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
     stamp "bench lines (CPU baseline, recall, parity at full size, boundary timings)"
-    for cfg in sift1m glove25 glove25_dot mnist784 random10k; do
-      timeout 600 python bench.py --config $cfg --steps 20 --warmup 5 > $O/bench_$cfg.json 2> $O/bench_$cfg.log
+    for cfg in sift1m glove25 glove25_dot mnist784 mnist784_hbm random10k; do
+      timeout 900 python bench.py --config $cfg --steps 20 --warmup 5 > $O/bench_$cfg.json 2> $O/bench_$cfg.log
       echo "-- $cfg"; line < $O/bench_$cfg.json
       grep -E "built in" $O/bench_$cfg.log
     done
@@ -81,14 +81,14 @@ PY
     timeout 600 python bench.py --config sift1m --nq 100000 --steps 5 --warmup 2 --no-boundary --no-traffic > $O/bench_sift1m_nq100k.json 2> $O/bench_sift1m_nq100k.log
     line < $O/bench_sift1m_nq100k.json
     stamp "N = 2 as a plain command (both ranks on the one device)"
-    timeout 400 python bench.py --gpus 2 --share-device --backend nccl --nq 5000 --steps 10 --warmup 2 --no-cpu-baseline --no-recall \
+    timeout 600 python bench.py --gpus 2 --share-device --backend nccl --steps 5 --warmup 2 --no-cpu-baseline --no-recall \
         2> $O/bench_sift1m_n2_shared_device.log | grep '^{' > $O/bench_sift1m_n2_shared_device.json
     python -c "
 import json
 j=[json.loads(l) for l in open('$O/bench_sift1m_n2_shared_device.json') if l.startswith('{')][-1]
-print(j['value'], j['n_gpus'], j['gather_ms'], j['rccl'])" || tail -5 $O/bench_sift1m_n2_shared_device.log
+print(j['value'], j['n_gpus'], j['scaling'], j['config']['queries_total'], j['one_gpu_same_batch_queries_per_s'], j['gather_ms'], j['rccl'])" || tail -5 $O/bench_sift1m_n2_shared_device.log
     stamp "rocprofv3 per config"
-    for cfg in sift1m glove25 glove25_dot mnist784; do
+    for cfg in sift1m glove25 glove25_dot mnist784 mnist784_hbm; do
       timeout 600 tools/profile_round.sh ${R}_record/prof_$cfg --config $cfg > $O/prof_$cfg.log 2>&1
       python tools/summarize_profile.py $O/prof_$cfg > $O/rocprofv3_summary_$cfg.txt 2>&1
       cp $(find $O/prof_$cfg/kt -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$cfg.csv 2>/dev/null
