@@ -24,7 +24,7 @@ if "commit" not in prov:
     except Exception:
         pass
 out = {}
-for cfg in ("sift1m", "glove25", "glove25_dot", "mnist784"):
+for cfg in ("sift1m", "glove25", "glove25_dot", "mnist784", "mnist784_hbm"):
     sp = os.path.join(ROOT, "profiles", f"{tag}_{cfg}_rocprofv3_summary.txt")
     bp = os.path.join(ROOT, "profiles", f"{tag}_bench_{cfg}.json")
     if not (os.path.exists(sp) and os.path.exists(bp)):
