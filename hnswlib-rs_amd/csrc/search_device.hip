@@ -44,6 +44,7 @@ Knobs read_knobs() {
     auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
     k.hash_bits = num("HNSWGPU_HASH_BITS", -1);
     k.no_sched = flag("HNSWGPU_NO_SCHED");
+    k.no_pair_descent = flag("HNSWGPU_NO_PAIR_DESCENT");
     k.no_inkernel = flag("HNSWGPU_NO_INKERNEL");
     k.strict_wg_per_cu = num("HNSWGPU_STRICT_WG_PER_CU", -1);
     k.cand_lds = num("HNSWGPU_CAND_LDS", -1);
@@ -425,7 +426,8 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
     device_ = device;
     dist_ = x.dist;
     bytes_ = 0;
-    descend_per_cu_.store(0);
+    descend_per_cu_[0].store(0);
+    descend_per_cu_[1].store(0);
 
     const uint64_t n = x.n, d = x.dimension;
     DeviceIndexView v{};
@@ -470,16 +472,19 @@ int DeviceIndex::upload(const FlatIndex& x, int device, std::string& err) {
         v.n_up_layers = top;
         std::vector<uint32_t> ptr((size_t)std::max(1u, top) * (n + 1), 0u);
         std::vector<uint32_t> ids;
+        uint64_t up_deg_max = 0;
         for (unsigned l = 1; l <= top; ++l) {
             uint32_t* p = ptr.data() + (size_t)(l - 1) * (n + 1);
             for (uint64_t f = 0; f < n; ++f) {
                 p[f] = (uint32_t)ids.size();
                 uint64_t b = x.nbr_ptr[f * NB_LAYER_MAX + l], e = x.nbr_ptr[f * NB_LAYER_MAX + l + 1];
                 ids.insert(ids.end(), x.nbr_flat.begin() + b, x.nbr_flat.begin() + e);
+                up_deg_max = std::max<uint64_t>(up_deg_max, e - b);
             }
             p[n] = (uint32_t)ids.size();
         }
         if (ids.empty()) ids.push_back(0);
+        up_deg_max_ = (uint32_t)std::min<uint64_t>(up_deg_max, 0xFFFFFFFFull);
         HIP_TRY(hipMalloc(&d_up_ptr_, ptr.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(d_up_ptr_, ptr.data(), ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&d_up_ids_, ids.size() * sizeof(uint32_t)));
@@ -641,11 +646,14 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     // first kernel of the call: rows padded to the row stride, the greedy descent of every query (pre[]), counters zeroed
     {
         const KernelSet& ks = kernel_set(kernel_metric());
-        int per_cu = descend_per_cu_.load();
+        // two queries per wavefront where every list above the search layer fits a half's 16 row slots (hnsw_descend_pair_kernel)
+        const bool pair = up_deg_max_ <= 16u && kernel_metric() < KM_SIMD8_FIRST && !knobs().no_pair_descent;
+        const size_t descend_lds = (pair ? 2u : 1u) * (size_t)tile_bytes + IDS_BYTES;
+        int per_cu = descend_per_cu_[pair].load();
         if (per_cu <= 0) {
-            HIP_TRY(ks.descend_occupancy(tile_bytes + IDS_BYTES, &per_cu));
+            HIP_TRY(ks.descend_occupancy(descend_lds, pair, &per_cu));
             per_cu = std::max(1, per_cu);
-            descend_per_cu_.store(per_cu);
+            descend_per_cu_[pair].store(per_cu);
         }
         // one launch -- or, when the rows are still being gathered into pinned memory, one per chunk: the device reads chunk i
         // across PCIe while the host fills chunk i + 1 (a few chunks: every launch costs a few microseconds of stream time)
@@ -662,7 +670,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             da.nrm2 = static_cast<const double*>(d_nrm2_);
             da.ctrl = lo == 0 ? static_cast<uint32_t*>(w.d_ctrl) : nullptr;
             da.ctrl_words = 16;
-            HIP_TRY(ks.launch_descend((uint32_t)std::min<uint64_t>(hi - lo, (uint64_t)per_cu * (uint64_t)num_cu_), stream, v_, da));
+            da.pair = pair ? 1u : 0u;
+            const uint64_t waves = pair ? (hi - lo + 1) / 2 : hi - lo;
+            HIP_TRY(ks.launch_descend((uint32_t)std::min<uint64_t>(waves, (uint64_t)per_cu * (uint64_t)num_cu_), stream, v_, da));
         }
     }
 

@@ -19,6 +19,7 @@ constexpr int ARITH_SCALAR = 0, ARITH_SIMD8 = 1;  // DeviceIndex::set_arithmetic
 struct Knobs {
     int hash_bits = -1;          // HNSWGPU_HASH_BITS: initial visited-table size (6..14)
     bool no_sched = false;       // HNSWGPU_NO_SCHED: searches in input order
+    bool no_pair_descent = false;  // HNSWGPU_NO_PAIR_DESCENT: one query per wavefront in the descent kernel whatever the index
     bool no_inkernel = false;    // HNSWGPU_NO_INKERNEL: strict ties resolved by the literal kernel only
     int strict_wg_per_cu = -1;   // HNSWGPU_STRICT_WG_PER_CU
     int cand_lds = -1;           // HNSWGPU_CAND_LDS
@@ -192,7 +193,8 @@ private:
     std::atomic<bool> strict_ties_{true};
     std::atomic<int> arith_{0};
     int kernel_metric() const;            // dist_, or its SIMD-order kernel variant
-    std::atomic<int> descend_per_cu_{0};  // resident workgroups per CU of the descent kernel (asked once)
+    std::atomic<int> descend_per_cu_[2] = {{0}, {0}};  // resident workgroups per CU of the descent kernel (asked once; [1]: two queries per wavefront)
+    uint32_t up_deg_max_ = 0;  // longest list above the search layer
 };
 
 int device_count();

@@ -43,6 +43,7 @@ struct DescendArgs {
     const double* nrm2;  // as in SearchArgs
     uint32_t* ctrl;      // the call's counters, zeroed by workgroup 0 (ctrl_words of them, <= 64)
     uint32_t ctrl_words;
+    uint32_t pair;       // two queries per wavefront (hnsw_descend_pair_kernel: lists above the search layer of <= 16 ids, scalar arithmetic)
 };
 
 struct SearchArgs {
@@ -174,7 +175,7 @@ struct KernelSet {
     // first kernel of a call: queries padded, greedy descent of every query (pre[]); then, batch scheduling, the queries in
     // descending order of the descent's distance
     hipError_t (*launch_descend)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const DescendArgs& a);
-    hipError_t (*descend_occupancy)(size_t lds, int* per_cu);
+    hipError_t (*descend_occupancy)(size_t lds, bool pair, int* per_cu);
     hipError_t (*launch_order)(hipStream_t stream, const PreDescent* pre, uint32_t n, uint32_t* order);
     // arithmetic tests: out[q][r] = dist(queries[q], rows[r]) through batch_dist, rows in batches of nf; or, pairs:
     // out[q] = dist(queries[q], rows[q])
