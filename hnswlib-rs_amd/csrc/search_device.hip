@@ -642,7 +642,7 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
 
     HIP_TRY(w.pre.ensure(nq * sizeof(PreDescent)));
     const uint32_t tile_bytes = tile_bytes_for(kernel_metric(), v_.row_stride);
-    HIP_TRY(hipEventRecord(w.ev_start, stream));
+    // (the call's events ride on its kernels: ev_start = start of the first descent launch, ev_ks / ev_ke = the first search launch)
     // first kernel of the call: rows padded to the row stride, the greedy descent of every query (pre[]), counters zeroed
     {
         const KernelSet& ks = kernel_set(kernel_metric());
@@ -672,7 +672,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
             da.ctrl_words = 16;
             da.pair = pair ? 1u : 0u;
             const uint64_t waves = pair ? (hi - lo + 1) / 2 : hi - lo;
-            HIP_TRY(ks.launch_descend((uint32_t)std::min<uint64_t>(waves, (uint64_t)per_cu * (uint64_t)num_cu_), stream, v_, da));
+            HIP_TRY(ks.launch_descend((uint32_t)std::min<uint64_t>(waves, (uint64_t)per_cu * (uint64_t)num_cu_), stream, v_, da,
+                                      LaunchEvents{lo == 0 ? w.ev_start : nullptr, nullptr}));
         }
     }
 
@@ -796,8 +797,9 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         if (kn.waves_per_cu > 0) per_cu = std::max(1, std::min(per_cu, kn.waves_per_cu));  // tuning hook
         uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, work);
         if (kn.trace_launch)  // diagnostics: what bounds the resident workgroups of this launch
-            std::fprintf(stderr, "[hnswgpu launch] %u queries, %d workgroups per CU (strict cap %d), %zu bytes of LDS each (literal heap: %u entries), table 2^%u cells, strict %d\n",
-                         work, per_cu, strict_cap, lds, a.cand_lds, a.tbits, (int)strict_kernel);
+            std::fprintf(stderr, "[hnswgpu launch] %u queries, %d workgroups per CU (strict cap %d), %zu bytes of LDS each (literal heap: %u entries), table 2^%u cells, strict %d, work list %s\n",
+                         work, per_cu, strict_cap, lds, a.cand_lds, a.tbits, (int)strict_kernel,
+                         qlist ? "sorted" : "input order");
         a.queries = w.qpad.as<float>();
         a.qlist = qlist;
         a.nq = work;
@@ -841,9 +843,8 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
         }
         // (the first launch finds the counters zeroed by the descent kernel; the flagged list spans relaunches)
         if (launches != 0) HIP_TRY(hipMemsetAsync(w.d_ctrl, 0, 16, stream));
-        if (launches == 0) HIP_TRY(hipEventRecord(w.ev_ks, stream));
-        HIP_TRY(ks.launch_search(slots, table, strict_kernel, grid, lds, stream, v_, a));
-        if (launches == 0) HIP_TRY(hipEventRecord(w.ev_ke, stream));
+        HIP_TRY(ks.launch_search(slots, table, strict_kernel, grid, lds, stream, v_, a,
+                                 launches == 0 ? LaunchEvents{w.ev_ks, w.ev_ke} : LaunchEvents{}));
         ++launches;
         volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);  // pinned: a true asynchronous copy
         HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 24, hipMemcpyDeviceToHost, stream));

@@ -2,6 +2,7 @@
 // (search_device.hip) and the per-metric kernel translation units (search_kernels_tu.hip, compiled per metric and part).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include "search_device.hpp"
 
@@ -161,20 +162,28 @@ struct LaneLabArgs {
 };
 hipError_t launch_lane_lab(hipStream_t stream, size_t lds, const LaneLabArgs& a);
 
+// Events bound to ONE kernel launch (hipExtLaunchKernelGGL): they take the kernel's own start / end time -- what rocprofv3's kernel
+// trace reports -- instead of the time of a marker packet in front of / behind it.  (The idle 6 us between the order kernel and
+// the search kernel are not the markers': they stay, bound or not -- tools/GPU_CALLS.md round 6, call 21.)  Null members: no event.
+struct LaunchEvents {
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+};
+
 // Three translation units per metric instantiate the kernels (search_kernels_tu.hip with -DHNSW_THIS_METRIC / -DHNSW_PART:
 // strict search kernels, lean search kernels, everything else) -- keeps the build parallel and the objects small.
 struct KernelSet {
     // search kernel: S in {1,2,4,16} result slots per lane, visited-table kind, strict (decisions that depend on the
     // reference's heap order are resolved with literal heaps inside the launch) or lean (such queries are only flagged)
     hipError_t (*launch_search)(int slots, int table, bool strict, uint32_t grid, size_t lds, hipStream_t stream,
-                                const DeviceIndexView& ix, const SearchArgs& a);
+                                const DeviceIndexView& ix, const SearchArgs& a, LaunchEvents ev);
     hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);
     hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
                                const SearchArgs& a, const ExactArgs& x);
     hipError_t (*exact_occupancy)(int ns, size_t lds, int* per_cu);
     // first kernel of a call: queries padded, greedy descent of every query (pre[]); then, batch scheduling, the queries in
     // descending order of the descent's distance
-    hipError_t (*launch_descend)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const DescendArgs& a);
+    hipError_t (*launch_descend)(uint32_t grid, hipStream_t stream, const DeviceIndexView& ix, const DescendArgs& a, LaunchEvents ev);
     hipError_t (*descend_occupancy)(size_t lds, bool pair, int* per_cu);
     hipError_t (*launch_order)(hipStream_t stream, const PreDescent* pre, uint32_t n, uint32_t* order);
     // arithmetic tests: out[q][r] = dist(queries[q], rows[r]) through batch_dist, rows in batches of nf; or, pairs:
