@@ -399,6 +399,8 @@ def filtered_measure(torch, H, lib, index, orc, n, d, k, ef, Q, cpu_queries, pct
             ts.append(time.perf_counter() - t0)
             kms.append(index.last_search_kernel_ms())
         st = stats.cpu().numpy().astype(np.int64)
+        if os.environ.get("HNSW_BENCH_DUMP_FILTERED"):  # profiling builds of the literal kernel put phase ticks into the counters
+            np.save(os.path.join(os.environ["HNSW_BENCH_DUMP_FILTERED"], f"filtered_{nq}_{pct}pct.npy"), st)
         nd, nx, ni = st[:, 0], st[:, 1], st[:, 2]
         dur_us = ((st[:, 5] - st[:, 4]) & 0xFFFFFFFF) / 100.0  # 10 ns ticks
         alg = int(nd.sum()) * d * 4 + int(ni.sum()) * 4 + int(nx.sum()) * 8 + nq * (d * 4 + k * 12)
