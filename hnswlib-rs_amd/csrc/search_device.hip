@@ -55,6 +55,9 @@ Knobs read_knobs() {
     k.host_threads = num("HNSWGPU_HOST_THREADS", -1);
     k.host_chunks = num("HNSWGPU_HOST_CHUNKS", -1);
     k.ffi_unpack = flag("HNSWGPU_FFI_UNPACK");
+    k.pair_search = num("HNSWGPU_PAIR_SEARCH", -1);
+    k.pair_tbits_delta = num("HNSWGPU_PAIR_TBITS_DELTA", 0);
+    k.pair_wg_per_cu = num("HNSWGPU_PAIR_WG_PER_CU", -1);
     return k;
 }
 std::atomic<const Knobs*> g_knobs{nullptr};
@@ -123,6 +126,7 @@ private:
     hipError_t status_ = hipSuccess;
 };
 
+constexpr bool PAIR_SEARCH_DEFAULT = false;  // hnsw_search_pair_kernel as the first pass of a batch without HNSWGPU_PAIR_SEARCH=1
 constexpr int STRICT_WG_PER_CU = 16;  // resident workgroups per CU of a strict launch: four waves per SIMD (see search_device)
 
 uint32_t ceil_log2(uint64_t x) {
@@ -743,7 +747,90 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     uint32_t n_flagged = 0, n_literal = 0;
     const uint32_t* qlist = scheduled ? w.order.as<uint32_t>() : nullptr;
     int pingpong = 0;
-    for (;;) {
+    bool all_done = false;
+    // ---- first pass with two queries per wavefront (hnsw_search_pair_kernel, search_pair.inc) where the index and the call allow it:
+    // ef <= 128 (4 result slots x 32 lanes), lists of <= 64 ids, 16-bit-cell tables, scalar arithmetic.  It answers the queries that
+    // never meet an equal distance and whose visited set fits its LDS table; the others come back on the retry list and go through
+    // the one-query kernels below (strict calls: ties included; lean calls: ties are flagged like the lean kernel flags them).
+    if (PAIR_SEARCH_DEFAULT ? kn.pair_search != 0 : kn.pair_search > 0) {
+        const int tbp = (int)tbits + kn.pair_tbits_delta;
+        const uint32_t tb = (uint32_t)std::max(6, std::min<int>(tbp, (int)std::min(14u, idbits + 3u)));
+        const bool ok = ef <= 128 && v_.deg_stride <= 64u && kernel_metric() < KM_SIMD8_FIRST && nq >= 512 && idbits >= tb - 3u && idbits - (tb - 3u) <= 13u &&
+                        idbits - (tb - 3u) >= 1u;
+        if (ok) {
+            const KernelSet& ks = kernel_set(kernel_metric());
+            SearchArgs a{};
+            a.tbits = tb;
+            a.restbits = idbits - (tb - 3u);
+            a.idbits = idbits;
+            a.tile_bytes = tile_bytes;
+            a.nrm2 = static_cast<const double*>(d_nrm2_);
+            const size_t lds = pair_lds_bytes(tile_bytes, tb, (uint32_t)ef);
+            int per_cu = 0;
+            HIP_TRY(ks.pair_occupancy(lds, &per_cu));
+            if (per_cu >= 1) {
+                if (kn.pair_wg_per_cu > 0) per_cu = std::min(per_cu, kn.pair_wg_per_cu);
+                const uint64_t npairs = (nq + 1) / 2;
+                const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)num_cu_, npairs);
+                if (kn.trace_launch)
+                    std::fprintf(stderr, "[hnswgpu launch] pair pass: %u queries, %d workgroups per CU, %zu bytes of LDS each, tables 2^%u cells\n",
+                                 work, per_cu, lds, tb);
+                a.queries = w.qpad.as<float>();
+                a.qlist = qlist;
+                a.nq = work;
+                a.k = (uint32_t)k;
+                a.ef = (uint32_t)ef;
+                a.work_counter = static_cast<uint32_t*>(w.d_ctrl);
+                a.overflow_count = static_cast<uint32_t*>(w.d_ctrl) + 1;
+                a.retry_out = w.retry[pingpong].as<uint32_t>();
+                a.out_ids = d_out_ids;
+                a.out_dists = d_out_dists;
+                a.out_layer = d_out_layer;
+                a.out_rank = d_out_rank;
+                a.out_counts = d_out_counts;
+                a.id_stride = layout.id_stride;
+                a.dist_stride = layout.dist_stride;
+                a.count_stride = layout.count_stride;
+                a.stats = stats;
+                a.pre = w.pre.as<PreDescent>();
+                a.tie_list = w.tie.as<uint32_t>();
+                a.pair_ties_to_retry = strict_ties ? 1u : 0u;
+                {   // HBM bitmaps for the halves whose table fills up: two slices per workgroup, within the 4 GiB budget
+                    a.bitmap_words = (v_.n + 31) / 32;
+                    const uint64_t slice = (uint64_t)a.bitmap_words * sizeof(uint32_t);
+                    const uint64_t blocks = std::min<uint64_t>(2ull * grid, std::max<uint64_t>(2, (4ull << 30) / slice));
+                    HIP_TRY(w.bitmap.ensure(blocks * slice));
+                    a.bitmap = w.bitmap.as<uint32_t>();
+                    a.bitmap_blocks = (uint32_t)blocks;
+                }
+                HIP_TRY(ks.launch_pair(grid, lds, stream, v_, a, LaunchEvents{w.ev_ks, w.ev_ke}));
+                ++launches;
+                volatile uint32_t* ctrl = static_cast<volatile uint32_t*>(w.h_ctrl);
+                HIP_TRY(hipMemcpyAsync(w.h_ctrl, w.d_ctrl, 24, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipEventRecord(w.ev_stop, stream));
+                stop_recorded_after = launches;
+                HIP_TRY(wait_stream(stream));
+                n_flagged = ctrl[4];
+                info.pair_retries = ctrl[1];
+                if (table != TABLE_GLOBAL_BITMAP && !env_forced) {  // table sizing feedback, as below
+                    uint32_t next = tbits_first;
+                    if ((uint64_t)ctrl[2] * 8 > nq && tbits_first < 14u) next = tbits_first + 1;
+                    else if ((uint64_t)ctrl[3] * 32 < nq && tbits_first > 8u) next = tbits_first - 1;
+                    std::lock_guard<std::mutex> g(meta_mu_);
+                    adapt_ef_ = ef;
+                    adapt_tbits_ = next;
+                }
+                if (ctrl[1] == 0) {
+                    all_done = true;
+                } else {
+                    work = ctrl[1];
+                    qlist = w.retry[pingpong].as<uint32_t>();
+                    pingpong ^= 1;
+                }
+            }
+        }
+    }
+    while (!all_done) {
         SearchArgs a{};
         size_t lds = lds_fixed;
         if (table != TABLE_GLOBAL_BITMAP) {

@@ -30,6 +30,9 @@ struct Knobs {
     int host_threads = -1;       // HNSWGPU_HOST_THREADS
     int host_chunks = -1;        // HNSWGPU_HOST_CHUNKS
     bool ffi_unpack = false;     // HNSWGPU_FFI_UNPACK
+    int pair_search = -1;        // HNSWGPU_PAIR_SEARCH: 1 / 0 = two queries per wavefront as the first pass of a batch where the index allows it / never
+    int pair_tbits_delta = 0;    // HNSWGPU_PAIR_TBITS_DELTA: the pair kernel's visited tables, in powers of two relative to the one-query kernels'
+    int pair_wg_per_cu = -1;     // HNSWGPU_PAIR_WG_PER_CU: cap on its resident workgroups per CU
 };
 const Knobs& knobs();
 void reload_knobs();
@@ -58,6 +61,7 @@ struct CallInfo {
     double main_ms = 0.0;    // first launch of the search kernel alone
     uint32_t launches = 0;
     uint32_t ties = 0;       // queries whose answer depended on the reference's heap order (resolved or flagged)
+    uint32_t pair_retries = 0;  // queries the two-per-wavefront first pass handed back to the one-query kernels
     uint32_t panics = 0;     // filtered search: queries on which the reference panics (src/hnsw.rs:973)
 };
 

@@ -70,6 +70,7 @@ struct SearchArgs {
     uint32_t cand_lds;      // strict ties: entries of the literal candidate heap kept in LDS (behind merge_list's buffer)
     uint32_t merge_entries; // LDS entries of merge_list's scatter buffer behind the visited table (64 S + 64, or 0: not used)
     uint32_t exact_first;   // strict ties, test hook: literal candidate heap from the first pop on
+    uint32_t pair_ties_to_retry;  // hnsw_search_pair_kernel: a query that met equal distances goes to the retry list (strict calls), not to tie_list
     hent_t* oplog;          // strict ties: [gridDim.x][oplog_cap] per-workgroup log of heap operations
     uint32_t oplog_cap;
     const double* nrm2;     // DistCosine: [n] squared norm of every point (f64 left-to-right sum of f32 squares); nullptr: the
@@ -178,6 +179,9 @@ struct KernelSet {
     hipError_t (*launch_search)(int slots, int table, bool strict, uint32_t grid, size_t lds, hipStream_t stream,
                                 const DeviceIndexView& ix, const SearchArgs& a, LaunchEvents ev);
     hipError_t (*occupancy)(int slots, int table, bool strict, size_t lds, int* per_cu);
+    // two queries per wavefront (hnsw_search_pair_kernel: ef <= 128, lists of <= 64 ids, 16-bit-cell tables, scalar arithmetic)
+    hipError_t (*launch_pair)(uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix, const SearchArgs& a, LaunchEvents ev);
+    hipError_t (*pair_occupancy)(size_t lds, int* per_cu);
     hipError_t (*launch_exact)(int ns, uint32_t grid, size_t lds, hipStream_t stream, const DeviceIndexView& ix,
                                const SearchArgs& a, const ExactArgs& x);
     hipError_t (*exact_occupancy)(int ns, size_t lds, int* per_cu);
@@ -207,6 +211,11 @@ struct KernelSet {
 // LDS in front of the id buffer: the query row; DistCosine keeps the query's squared norm (f64) behind it
 inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
     return ((row_stride * 4u + 15u) & ~15u) + (metric == DIST_COSINE || metric == KM_COSINE_SIMD8 ? 16u : 0u);
+}
+// LDS of a hnsw_search_pair_kernel workgroup: two query rows, two id buffers, two visited tables of 2^tb 16-bit cells, two mirrors of
+// the result array (ef entries), the candidates and the cr list of a round
+inline size_t pair_lds_bytes(uint32_t tile_bytes, uint32_t tb, uint32_t ef) {
+    return 2u * (size_t)tile_bytes + 2u * IDS_BYTES + 2u * ((size_t)2 << tb) + 2u * (size_t)((ef + 1u) & ~1u) * sizeof(hent_t) + 2u * 16u * sizeof(hent_t) + 2u * 16u * 4u;
 }
 // kernels_for<METRIC>(): defined in part 2 of that metric's translation units (search_kernels_tu.hip)
 template <int METRIC> const KernelSet& kernels_for();
