@@ -71,3 +71,32 @@ def test_pair_first_pass_hands_back_ties_and_full_tables(native, oracle, tmp_pat
     knob("HNSWGPU_HASH_BITS", "9")
     _check(native, oracle, h2, o2, Q2, 10, 128, knob, min_first_pass=0.0)
     knob("HNSWGPU_HASH_BITS", None)
+
+
+def test_default_policy_takes_the_first_pass_for_large_strict_cosine_batches(native, oracle, tmp_path, knob, capfd):
+    """Without HNSWGPU_PAIR_SEARCH a strict DistCosine batch of >= 40 000 queries goes through the pair pass (search_device.hip,
+    PAIR_SEARCH_AUTO_MIN_QUERIES): same answers as with the pass switched off and as the oracle; most queries answered by it."""
+    X, o, h = build_pair(native, oracle, tmp_path, 6000, 25, 24, 100, "DistCosine", seed=91, tag="auto")
+    Q = uniform(40960, 25, 13)
+    k, ef = 10, 128
+    ref = o.parallel_search(Q, k, ef)
+    knob("HNSWGPU_PAIR_SEARCH", None)
+    knob("HNSWGPU_TRACE_LAUNCH", "1")
+    capfd.readouterr()
+    ids_a, d_a, cnt_a, st_a = _device_call_with_stats(native, h, Q, k, ef)
+    assert "pair pass" in capfd.readouterr().err
+    knob("HNSWGPU_PAIR_SEARCH", "0")
+    ids_s, d_s, cnt_s, st_s = _device_call_with_stats(native, h, Q, k, ef)
+    assert "pair pass" not in capfd.readouterr().err
+    knob("HNSWGPU_TRACE_LAUNCH", None)
+    knob("HNSWGPU_PAIR_SEARCH", None)
+    assert np.array_equal(ids_a, ids_s) and np.array_equal(d_a, d_s) and np.array_equal(cnt_a, cnt_s)
+    assert np.array_equal(cnt_a, ref.counts.astype(np.uint32))
+    assert np.array_equal(ids_a, ref.ids.astype(np.uint64)) and np.array_equal(d_a, ref.dists.view(np.uint32))
+    assert np.mean(st_a[:, 3] == 0) > 0.5 and np.mean(st_s[:, 3] == 0) > 0.5
+    # (the pass leaves bit 2 of word 6 clear and never reports a literal pop: its queries carry status 0 and flags 0)
+    h.set_strict_ties(False)
+    ids_l, d_l, cnt_l, st_l = _device_call_with_stats(native, h, Q, k, ef)   # lean calls keep the one-query kernels by default
+    h.set_strict_ties(True)
+    tie_free = (st_l[:, 7] & 1) == 0
+    assert np.array_equal(ids_l[tie_free], ids_a[tie_free])
