@@ -63,7 +63,7 @@ def sh(c):
     try: return subprocess.run(c, shell=True, capture_output=True, text=True, timeout=20).stdout.strip()
     except Exception: return ""
 h = hashlib.sha256()
-for f in ("hnswlib-rs_amd/csrc/search_kernels.inc", "hnswlib-rs_amd/csrc/search_device.hip", "hnswlib-rs_amd/csrc/search_launchers.inc", "bench.py"):
+for f in ("hnswlib-rs_amd/csrc/search_kernels.inc", "hnswlib-rs_amd/csrc/search_pair.inc", "hnswlib-rs_amd/csrc/search_device.hip", "hnswlib-rs_amd/csrc/search_launchers.inc", "bench.py"):
     h.update(open(f, "rb").read())
 print(json.dumps({"utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": socket.gethostname(),
                   "gpu": sh("rocm-smi --showproductname --csv | tail -n +2 | head -1")[:120], "gpu_unique_id": sh("rocm-smi --showuniqueid --csv | tail -n +2 | head -1")[:80],
