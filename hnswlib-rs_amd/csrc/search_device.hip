@@ -126,7 +126,7 @@ private:
     hipError_t status_ = hipSuccess;
 };
 
-constexpr uint64_t PAIR_SEARCH_AUTO_MIN_QUERIES = 40000;  // hnsw_search_pair_kernel as the first pass of a strict DistCosine batch of at least this many queries
+constexpr uint64_t PAIR_SEARCH_AUTO_MIN_QUERIES = 40000;  // hnsw_search_pair_kernel as the first pass of a strict DistCosine / DistDot batch (rows of one 128-byte line) of at least this many queries
 constexpr int STRICT_WG_PER_CU = 16;  // resident workgroups per CU of a strict launch: four waves per SIMD (see search_device)
 
 uint32_t ceil_log2(uint64_t x) {
@@ -752,10 +752,12 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     // ef <= 128 (4 result slots x 32 lanes), lists of <= 64 ids, 16-bit-cell tables, scalar arithmetic.  It answers the queries that
     // never meet an equal distance and whose visited set fits its LDS table; the others come back on the retry list and go through
     // the one-query kernels below (strict calls: ties included; lean calls: ties are flagged like the lean kernel flags them).
-    // Default (no HNSWGPU_PAIR_SEARCH): where it was measured to pay -- strict DistCosine calls of tens of thousands of queries (config 3 at
-    // 100 000 per call: 9.6 M against 7.95 M queries/s; at 10 000 per call the second launch for the tie queries costs more than the
-    // pass gains, and the f32 metrics gain nothing: profiles/r06_pair_search/README.md).
-    const bool pair_auto = kernel_metric() == DIST_COSINE && strict_ties && nq >= PAIR_SEARCH_AUTO_MIN_QUERIES;
+    // Default (no HNSWGPU_PAIR_SEARCH): where it was measured to pay -- strict calls of tens of thousands of queries on short rows with
+    // DistCosine or DistDot (config 3 at 100 000 per call: 9.75 M against 7.93 M queries/s, config 3': 10.30 M against 9.45 M; both
+    // cross over at ~30 000 per call; at 10 000 the second launch for the tie queries costs more than the pass gains, rows of several
+    // 128-byte lines gain nothing: profiles/r06_pair_search/README.md).
+    const bool pair_auto = (kernel_metric() == DIST_COSINE || kernel_metric() == DIST_DOT) && v_.row_stride <= 32u && strict_ties &&
+                           nq >= PAIR_SEARCH_AUTO_MIN_QUERIES;
     if (kn.pair_search > 0 || (kn.pair_search < 0 && pair_auto)) {
         const int tbp = (int)tbits + kn.pair_tbits_delta;
         const uint32_t tb = (uint32_t)std::max(6, std::min<int>(tbp, (int)std::min(14u, idbits + 3u)));

@@ -31,7 +31,7 @@ struct Knobs {
     int host_chunks = -1;        // HNSWGPU_HOST_CHUNKS
     bool ffi_unpack = false;     // HNSWGPU_FFI_UNPACK
     int pair_search = -1;        // HNSWGPU_PAIR_SEARCH: 1 / 0 = two queries per wavefront as the first pass of a batch where the index allows it / never
-                                 // (unset: strict DistCosine batches of >= 40 000 queries)
+                                 // (unset: strict DistCosine / DistDot batches of >= 40 000 queries on rows of one 128-byte line)
     int pair_tbits_delta = 0;    // HNSWGPU_PAIR_TBITS_DELTA: the pair kernel's visited tables, in powers of two relative to the one-query kernels'
     int pair_wg_per_cu = -1;     // HNSWGPU_PAIR_WG_PER_CU: cap on its resident workgroups per CU
 };

@@ -215,7 +215,7 @@ inline uint32_t tile_bytes_for(int metric, uint32_t row_stride) {
 // LDS of a hnsw_search_pair_kernel workgroup: two query rows, two id buffers, two visited tables of 2^tb 16-bit cells, two mirrors of
 // the result array (ef entries), the candidates and the cr list of a round
 inline size_t pair_lds_bytes(uint32_t tile_bytes, uint32_t tb, uint32_t ef) {
-    return 2u * (size_t)tile_bytes + 2u * IDS_BYTES + 2u * ((size_t)2 << tb) + 2u * (size_t)((ef + 1u) & ~1u) * sizeof(hent_t) + 2u * 16u * sizeof(hent_t) + 2u * 16u * 4u;
+    return 2u * (size_t)tile_bytes + 2u * IDS_BYTES + 2u * ((size_t)2 << tb) + 2u * (size_t)((ef + 2u) & ~1u) * sizeof(hent_t) + 2u * 16u * sizeof(hent_t) + 2u * 16u * 4u;
 }
 // kernels_for<METRIC>(): defined in part 2 of that metric's translation units (search_kernels_tu.hip)
 template <int METRIC> const KernelSet& kernels_for();

@@ -73,11 +73,12 @@ def test_pair_first_pass_hands_back_ties_and_full_tables(native, oracle, tmp_pat
     knob("HNSWGPU_HASH_BITS", None)
 
 
-def test_default_policy_takes_the_first_pass_for_large_strict_cosine_batches(native, oracle, tmp_path, knob, capfd):
-    """Without HNSWGPU_PAIR_SEARCH a strict DistCosine batch of >= 40 000 queries goes through the pair pass (search_device.hip,
-    PAIR_SEARCH_AUTO_MIN_QUERIES): same answers as with the pass switched off and as the oracle; most queries answered by it."""
-    X, o, h = build_pair(native, oracle, tmp_path, 6000, 25, 24, 100, "DistCosine", seed=91, tag="auto")
-    Q = uniform(40960, 25, 13)
+@pytest.mark.parametrize("dist,normalize", [("DistCosine", False), ("DistDot", True)])
+def test_default_policy_takes_the_first_pass_for_large_strict_cosine_batches(native, oracle, tmp_path, knob, capfd, dist, normalize):
+    """Without HNSWGPU_PAIR_SEARCH a strict DistCosine / DistDot batch of >= 40 000 queries on short rows goes through the pair pass
+    (search_device.hip, PAIR_SEARCH_AUTO_MIN_QUERIES): same answers as with the pass switched off and as the oracle."""
+    X, o, h = build_pair(native, oracle, tmp_path, 6000, 25, 24, 100, dist, seed=91, normalize=normalize, tag="auto")
+    Q = normalized(40960, 25, 13) if normalize else uniform(40960, 25, 13)
     k, ef = 10, 128
     ref = o.parallel_search(Q, k, ef)
     knob("HNSWGPU_PAIR_SEARCH", None)
