@@ -749,9 +749,10 @@ int DeviceIndex::search_device(const float* d_queries, uint64_t nq, uint64_t d, 
     int pingpong = 0;
     bool all_done = false;
     // ---- first pass with two queries per wavefront (hnsw_search_pair_kernel, search_pair.inc) where the index and the call allow it:
-    // ef <= 128 (4 result slots x 32 lanes), lists of <= 64 ids, 16-bit-cell tables, scalar arithmetic.  It answers the queries that
-    // never meet an equal distance and whose visited set fits its LDS table; the others come back on the retry list and go through
-    // the one-query kernels below (strict calls: ties included; lean calls: ties are flagged like the lean kernel flags them).
+    // ef <= 128 (4 result slots x 32 lanes), lists of <= 64 ids, 16-bit-cell tables, scalar arithmetic.  It answers every query that
+    // meets none of the three places where equal distances make the reference's answer depend on its heaps' order (DESIGN.md section
+    // 6); those come back on the retry list and go through the one-query kernels below (strict calls; lean calls flag them like the
+    // lean kernel does).  A visited set that outgrows its LDS table moves to an HBM bitmap slice inside the launch.
     // Default (no HNSWGPU_PAIR_SEARCH): where it was measured to pay -- strict calls of tens of thousands of queries on short rows with
     // DistCosine or DistDot (config 3 at 100 000 per call: 9.75 M against 7.93 M queries/s, config 3': 10.30 M against 9.45 M; both
     // cross over at ~30 000 per call; at 10 000 the second launch for the tie queries costs more than the pass gains, rows of several
