@@ -18,6 +18,8 @@ int DeviceIndex::search_host_staged(const float*, const float* const*, uint64_t,
 int DeviceIndex::kernel_metric() const { return dist_; }
 CallInfo DeviceIndex::last_call() const { return CallInfo{}; }
 int device_count() { return 0; }
+const Knobs& knobs() { static const Knobs k; return k; }  // (the hooks live in search_device.hip: defaults here)
+void reload_knobs() {}
 void* pinned_alloc(size_t, void**) { return nullptr; }  // (no device: the callers fall back to ordinary memory)
 void pinned_free(void*) {}
 namespace {
@@ -33,4 +35,7 @@ public:
 }  // namespace
 std::unique_ptr<BuildSearchBackend> make_device_build_backend(int) { return std::unique_ptr<BuildSearchBackend>(new NoDeviceBackend()); }
 int eval_distance_matrix_device(int, const float*, uint64_t, const float*, uint64_t, uint64_t, uint32_t, bool, float*, std::string& err, int) { err = kNoDev; return ERR_DEVICE; }
+int gather_sharded_answers(const int*, int, const uint64_t*, uint64_t, const uint64_t* const*, const float* const*, const uint8_t* const*, const int32_t* const*,
+                           const uint32_t* const*, int, uint64_t*, float*, uint8_t*, int32_t*, uint32_t*, void*, std::string& err) { err = kNoDev; return ERR_DEVICE; }
+int lane_lab_device(int, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint32_t*, uint32_t, uint32_t*, uint32_t, std::string& err) { err = kNoDev; return ERR_DEVICE; }
 }  // namespace hnswgpu
